@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def load_golden(name):
+    """npz -> {key: torch tensor}; loaded with allow_pickle=False (data only)."""
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def sub(d, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def relerr(a, b):
+    """max-norm relative error |a-b|_inf / max(|b|_inf, tiny)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden_tiny():
+    return load_golden("tiny_step.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_odd3():
+    return load_golden("odd3_step.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    return load_golden("ops.npz")

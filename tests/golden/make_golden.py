@@ -1,0 +1,174 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference); the outputs (*.npz,
+data only) are committed, the reference source never is.  Usage:
+
+    python tests/golden/make_golden.py
+
+What is imported from the reference: the torch-only network files
+``src/models/components/shared_encoder.py`` (SharedEncoder, TimeEmbedding,
+DoubleConv, Down) and ``src/models/components/task_decoders.py``
+(FlowMatchingDecoder, Up).  The LightningModules cannot be imported here
+(lightning / torchcfm / torchdyn / wandb are not installed), so the five lines
+of step logic around the network (conditional_flow_matching.py:53-74,
+conditional_flow_matching_multitask.py:134-155) are driven from this script with
+stock torch: ``xt = t*x1 + (1-t)*x0``, ``ut = x1 - x0`` (sigma = 0, explicit t),
+``loss = mean((v-ut)**2)``, ``torch.optim.Adam(lr=1e-4, weight_decay=1e-5)``
+(configs/model/conditional_flow_matching_multitask.yaml:3-7).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("S2S_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+from src.models.components.shared_encoder import DoubleConv, Down, SharedEncoder, TimeEmbedding  # noqa: E402
+from src.models.components.task_decoders import FlowMatchingDecoder, Up  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 1984  # configs/experiment/gray_matter/simple_flow_matching.yaml:16
+
+
+def npy(t):
+    return t.detach().cpu().clone().numpy()  # clone: state tensors are updated in place later
+
+
+def full_state(enc, dec):
+    sd = {"encoder." + k: v for k, v in enc.state_dict().items()}
+    sd.update({"flow_decoder." + k: v for k, v in dec.state_dict().items()})
+    return sd
+
+
+def named_params(enc, dec):
+    d = {"encoder." + k: p for k, p in enc.named_parameters()}
+    d.update({"flow_decoder." + k: p for k, p in dec.named_parameters()})
+    return d
+
+
+def flow(enc, dec, temb, t, x):
+    b, skips = enc(x)
+    return dec(b, skips, temb(t))
+
+
+def make_step_fixture(name, feats, hw, batch, n_steps, tdim):
+    torch.manual_seed(SEED)
+    enc = SharedEncoder(3, list(feats))
+    dec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
+    temb = TimeEmbedding(tdim)
+    g = torch.Generator().manual_seed(SEED)
+    out = {}
+    for k, v in full_state(enc, dec).items():
+        out["init/" + k] = npy(v)
+    params = named_params(enc, dec)
+    opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=1e-4, weight_decay=1e-5)
+    enc.train(); dec.train()
+    for s in range(n_steps):
+        x0 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
+        x1 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
+        t = torch.rand(batch, generator=g)
+        tb = t.view(-1, 1, 1, 1)
+        xt = tb * x1 + (1 - tb) * x0
+        ut = x1 - x0
+        opt.zero_grad()
+        v = flow(enc, dec, temb, t, xt)
+        loss = torch.mean((v - ut) ** 2)
+        loss.backward()
+        out[f"step{s}/x0"] = npy(x0); out[f"step{s}/x1"] = npy(x1); out[f"step{s}/t"] = npy(t)
+        out[f"step{s}/v"] = npy(v); out[f"step{s}/loss"] = npy(loss)
+        for k, p in params.items():
+            out[f"step{s}/grad/" + k] = npy(p.grad)
+        opt.step()
+        for k, val in full_state(enc, dec).items():
+            out[f"step{s}/after/" + k] = npy(val)
+    # eval-mode fixed-step Euler from the last source batch (BASELINE.json config 4, tiny)
+    enc.eval(); dec.eval()
+    n_euler = 50
+    with torch.no_grad():
+        x = x0[:2].clone()
+        out["euler/x_start"] = npy(x)
+        for k in range(n_euler):
+            tk = torch.full((x.shape[0],), k / n_euler)
+            x = x + (1.0 / n_euler) * flow(enc, dec, temb, tk, x)
+        out["euler/x_end"] = npy(x)
+        out["euler/n_steps"] = np.int64(n_euler)
+        tq = torch.tensor([0.0, 0.37])
+        out["eval/t"] = npy(tq)
+        out["eval/v"] = npy(flow(enc, dec, temb, tq, x0[:2]))
+    out["meta/features"] = np.asarray(feats, dtype=np.int64)
+    out["meta/time_emb_dim"] = np.int64(tdim)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "loss", [float(out[f"step{s}/loss"]) for s in range(n_steps)])
+
+
+def make_ops_fixture():
+    torch.manual_seed(SEED + 1)
+    g = torch.Generator().manual_seed(SEED + 1)
+    out = {}
+
+    # TimeEmbedding
+    t = torch.tensor([0.0, 0.125, 0.5, 0.999, 1.0])
+    for dim in (32, 256):
+        out[f"temb{dim}/t"] = npy(t)
+        out[f"temb{dim}/y"] = npy(TimeEmbedding(dim)(t))
+
+    # DoubleConv fwd + all grads, training mode, and running stats afterwards
+    dc = DoubleConv(8, 16).train()
+    x = (torch.rand(2, 8, 12, 10, generator=g) * 2 - 1).requires_grad_(True)
+    for k, v in dc.state_dict().items():
+        out["dc/init/" + k] = npy(v)
+    y = dc(x)
+    w = torch.rand(y.shape, generator=g) - 0.5
+    (y * w).sum().backward()
+    out["dc/x"] = npy(x); out["dc/y"] = npy(y); out["dc/w"] = npy(w); out["dc/dx"] = npy(x.grad)
+    for k, p in dc.named_parameters():
+        out["dc/grad/" + k] = npy(p.grad)
+    for k, v in dc.state_dict().items():
+        out["dc/after/" + k] = npy(v)
+    dc.eval()
+    out["dc/y_eval"] = npy(dc(x.detach()))
+
+    # Down (maxpool + DoubleConv) on an odd-sized map (floor pooling)
+    dn = Down(8, 16).train()
+    x = (torch.rand(2, 8, 13, 10, generator=g) * 2 - 1).requires_grad_(True)
+    for k, v in dn.state_dict().items():
+        out["down/init/" + k] = npy(v)
+    y = dn(x)
+    w = torch.rand(y.shape, generator=g) - 0.5
+    (y * w).sum().backward()
+    out["down/x"] = npy(x); out["down/y"] = npy(y); out["down/w"] = npy(w); out["down/dx"] = npy(x.grad)
+    for k, p in dn.named_parameters():
+        out["down/grad/" + k] = npy(p.grad)
+
+    # Up with a skip one pixel larger in both directions (exercises the F.pad branch)
+    up = Up(16 + 8, 8).train()
+    lo = (torch.rand(2, 16, 5, 6, generator=g) * 2 - 1).requires_grad_(True)
+    sk = (torch.rand(2, 8, 11, 13, generator=g) * 2 - 1).requires_grad_(True)
+    for k, v in up.state_dict().items():
+        out["up/init/" + k] = npy(v)
+    y = up(lo, sk)
+    w = torch.rand(y.shape, generator=g) - 0.5
+    (y * w).sum().backward()
+    out["up/lo"] = npy(lo); out["up/skip"] = npy(sk); out["up/y"] = npy(y); out["up/w"] = npy(w)
+    out["up/dlo"] = npy(lo.grad); out["up/dskip"] = npy(sk.grad)
+    for k, p in up.named_parameters():
+        out["up/grad/" + k] = npy(p.grad)
+
+    # bare bilinear x2 (align_corners=True) and 2x2 max-pool
+    xs = torch.rand(1, 2, 7, 4, generator=g)
+    out["bilinear/x"] = npy(xs)
+    out["bilinear/y"] = npy(torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)(xs))
+    out["pool/x"] = npy(xs)
+    out["pool/y"] = npy(torch.nn.MaxPool2d(2)(xs))
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
+    make_step_fixture("tiny_step.npz", (16, 32), (64, 64), 4, 2, 32)
+    # three levels, non-square, odd at level 1 (38 -> 19 -> 9; 9*2=18 vs 19 -> pad branch)
+    make_step_fixture("odd3_step.npz", (8, 16, 24), (38, 44), 2, 1, 16)
+    make_ops_fixture()
