@@ -1,0 +1,141 @@
+/* stain2stain_hip.h -- C ABI of libstain2stain_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (nirschl-lab/stain2stain) has no FFI: its hot path is stock torch.nn layers selected
+ * through Hydra `_target_` strings (configs/model/*.yaml).  These entry points are therefore
+ * build-defined; each one names the reference computation it replaces.  The Python classes in
+ * stain2stain_amd/ (same constructor signatures and state_dict keys as the reference's
+ * SharedEncoder / FlowMatchingDecoder / TimeEmbedding) bind them through ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative S2S_ERR_* code; nothing throws across the ABI
+ *   - all pointers are DEVICE pointers unless stated otherwise; the caller owns every buffer,
+ *     kernels never allocate; `stream` is a hipStream_t passed as void*
+ *   - dtype: S2S_BF16 (0) = bf16 tensors, bf16 MFMA, fp32 accumulate;
+ *            S2S_F32 (1)  = fp32 tensors; MFMA products formed from a hi/lo bf16 split (3 MFMAs)
+ *   - activation tensors are NHWC "views": element (n,h,w,c) lives at base[((n*H+h)*W+w)*ld + c];
+ *     ld (pixel stride, elements) lets a channel slice of a wider buffer be used in place.
+ *     Channel counts and ld must be multiples of 8, base pointers 16-byte aligned.
+ *   - the image tensors at the network boundary are NCHW contiguous fp32 (the reference's layout).
+ */
+#ifndef STAIN2STAIN_HIP_H
+#define STAIN2STAIN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2S_OK 0
+#define S2S_ERR_SHAPE (-1)
+#define S2S_ERR_ALIGN (-2)
+#define S2S_ERR_DTYPE (-3)
+#define S2S_ERR_LAUNCH (-4)
+#define S2S_ERR_NULL (-5)
+
+#define S2S_BF16 0
+#define S2S_F32 1
+
+/* ---- 3x3 convolution, MFMA implicit GEMM (conv3x3_mfma.hip) -------------------------------------
+ * nn.Conv2d(k=3, padding=1) of DoubleConv: src/models/components/shared_encoder.py:15,18,
+ * task_decoders.py:15,18.  Input = channels [0,c0) of x0 followed by [0,c1) of x1 (x1 may be NULL with
+ * c1 = 0): the torch.cat([skip, up], dim=1) of task_decoders.py:49 without the copy.
+ * w_packed: s2s_pack_conv3x3 output (forward layout for the forward pass, dgrad layout + swapped channel
+ * roles for the data gradient).  stat_part (optional): float[s2s_conv3x3_stat_blocks()][2][Cout] partial
+ * (sum, sum of squares) of the stored values per output channel, for BatchNorm.  ep_scale/ep_shift
+ * (optional, both or neither) and relu: y = relu?((acc + bias) * scale + shift) -- eval-mode BatchNorm
+ * folded into the epilogue. */
+int s2s_conv3x3_stat_blocks(int B, int H, int W, int Cout);
+int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                     const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                     const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W, int Cout,
+                     void* stream);
+
+/* ---- 3x3 convolution weight gradient (conv3x3_wgrad_mfma.hip) -----------------------------------
+ * autograd's conv2d weight gradient for the same layers.  part: float[splits][9][Cout][c0+c1] scratch;
+ * grad_oihw: float[Cout][c0+c1][3][3], overwritten or accumulated. */
+int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
+                           const void* x1, int ld1, int c1, float* part, float* grad_oihw, int accumulate,
+                           int B, int H, int W, void* stream);
+
+/* ---- stem and head (conv_edge.hip) ----------------------------------------------------------------
+ * stem: first conv of SharedEncoder.inc (shared_encoder.py:15,67), NCHW fp32 image (Cin <= 8) -> NHWC.
+ * head: FlowMatchingDecoder.outc, Conv2d(k=1) to Cout <= 4 (task_decoders.py:100,132), NHWC -> NCHW fp32. */
+int s2s_stem_stat_blocks(int B, int H, int W);
+int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
+                         float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream);
+int s2s_stem_wgrad_blocks(int B, int H, int W);
+/* part: float[blocks][Cout][Cin*9+1]; dbias may be NULL */
+int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part, float* dw_oihw,
+                           float* dbias, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
+int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float* y_nchw, int B,
+                         int H, int W, int C, int Cout, void* stream);
+int s2s_head_wgrad_blocks(int B, int H, int W);
+/* part: float[blocks][Cout][C+1] */
+int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void* x, int ldx, const float* w, void* dx, int lddx,
+                         float* part, float* dw, float* dbias, int accumulate, int B, int H, int W, int C, int Cout,
+                         void* stream);
+
+/* ---- BatchNorm2d + ReLU (+ MaxPool2d(2)) (norm_act.hip) -------------------------------------------
+ * nn.BatchNorm2d(eps 1e-5, momentum 0.1) -> nn.ReLU of DoubleConv (shared_encoder.py:16-20) and the
+ * nn.MaxPool2d(2) of the following Down block (shared_encoder.py:33). */
+int s2s_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long* num_batches_tracked, float momentum, float eps,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+int s2s_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* y = relu(x*scale+shift); pool (optional) = 2x2/stride-2 max of y, floor mode */
+int s2s_bn_relu_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,
+                      void* pool, int ldp, int B, int H, int W, int C, void* stream);
+int s2s_maxpool2(int dtype, const void* x, int ldx, void* pool, int ldp, int B, int H, int W, int C, void* stream);
+int s2s_bn_bwd_blocks(int B, int H, int W, int C);
+/* g1: gradient wrt the ReLU output (may be NULL if gp given); gp: gradient wrt the pooled output (may be
+ * NULL); y/x: saved ReLU output / conv output; work: float[4*blocks*C + 2*C];
+ * dbias_conv (optional): gradient of the preceding conv's bias = per-channel sum of dx. */
+int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const void* y, int ldy,
+                    const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                    float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx, float* work, int B, int H,
+                    int W, int C, void* stream);
+
+/* ---- bilinear x2, align_corners=True (+ F.pad to the skip size) (resample.hip) --------------------
+ * nn.Upsample + F.pad of Up.forward (task_decoders.py:34,42-47); bias_nc (optional, float[B][C]) is added
+ * to the input first: x = bottleneck + t[:, :, None, None] (task_decoders.py:119-125). */
+int s2s_upsample2x_bilinear_ac_fwd(int dtype, const void* x, int ldx, const float* bias_nc, void* y, int ldy, int B,
+                                   int Hin, int Win, int Hout, int Wout, int C, void* stream);
+int s2s_upsample2x_bilinear_ac_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int B, int Hin, int Win,
+                                   int Hout, int Wout, int C, void* stream);
+int s2s_pixel_sum(int dtype, const void* x, int ldx, float* out_nc, int B, int HW, int C, int accumulate,
+                  void* stream);
+
+/* ---- flow matching glue (flow.hip) --------------------------------------------------------------- */
+/* TimeEmbedding.forward, shared_encoder.py:114-135 */
+int s2s_time_embedding(const float* t, float* out, int B, int dim, void* stream);
+/* nn.Linear / nn.SiLU of FlowMatchingDecoder.time_mlp, time_proj (task_decoders.py:82-89) */
+int s2s_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);
+int s2s_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int accumulate,
+                   int B, int K, int N, void* stream);
+int s2s_silu_fwd(const float* h, float* a, int n, void* stream);
+int s2s_silu_bwd(const float* h, const float* da, float* dh, int n, void* stream);
+/* xt = t*x1 + (1-t)*x0 + sigma*eps, ut = x1 - x0 (conditional_flow_matching.py:66; torchcfm 1.0.7) */
+int s2s_cfm_sample(const float* x0, const float* x1, const float* t, const float* eps, float sigma, float* xt,
+                   float* ut, int B, long per_sample, void* stream);
+/* loss = mean((v-u)^2) (conditional_flow_matching.py:72); dv optional; work: double[1024] */
+int s2s_mse_loss(const float* v, const float* u, float* dv, float grad_scale, float* loss, double* work, long count,
+                 void* stream);
+int s2s_axpy(float* x, const float* y, float a, long n, void* stream);
+int s2s_fill_f32(float* x, float v, long n, void* stream);
+
+/* ---- optimiser, packing, layout (optim.hip) ------------------------------------------------------ */
+/* torch.optim.Adam step over a flat fp32 buffer (configs/model/*.yaml:3-7) */
+int s2s_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, void* stream);
+long s2s_pack_conv3x3_fwd_elems(int Cout, int Cin);
+long s2s_pack_conv3x3_dgrad_elems(int Cout, int Cin);
+int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, void* stream);
+int s2s_nchw_to_nhwc(int dtype, const float* x_nchw, void* y, int ldy, int B, int C, int H, int W, void* stream);
+int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accumulate, int B, int C, int H, int W,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAIN2STAIN_HIP_H */

@@ -119,8 +119,10 @@ def maxpool2(x: Tensor) -> Tensor:
     """2x2 / stride 2 max pooling, floor mode (odd trailing row/col dropped)."""
     b, c, h, w = x.shape
     ho, wo = h // 2, w // 2
-    win = x[:, :, : 2 * ho, : 2 * wo].reshape(b, c, ho, 2, wo, 2)
-    return win.amax(dim=(3, 5))
+    win = x[:, :, : 2 * ho, : 2 * wo].reshape(b, c, ho, 2, wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, ho, wo, 4)
+    # first maximum in (0,0),(0,1),(1,0),(1,1) order takes the value AND the gradient (ATen max_pool2d)
+    idx = win.detach().argmax(dim=-1, keepdim=True)
+    return win.gather(-1, idx).squeeze(-1)
 
 
 def _ac_axis(n_in: int, n_out: int):

@@ -1,0 +1,363 @@
+// 3x3 / stride 1 / pad 1 convolution, NHWC, im2col-free implicit GEMM on MFMA (gfx950).
+//
+// Replaces the ATen conv2d behind nn.Conv2d(k=3, padding=1) of the reference's DoubleConv
+// (src/models/components/shared_encoder.py:15,18; task_decoders.py:15,18) in the forward pass, and
+// the data-gradient of the same layers in the backward pass (same kernel, weights packed
+// flipped/transposed by s2s_pack_conv3x3).
+//
+// Decomposition: D[pixel][cout] = sum_{tap, cin} X[pixel (+) tap][cin] * Wp[tap][cout][cin]
+//   * one workgroup (256 threads = 4 waves) owns a TH x TW spatial tile of one image and BN output
+//     channels; the accumulators (fp32) live in registers for the whole K loop.
+//   * K loop: input channels in chunks of 32.  Per chunk the (TH+2) x (TW+2) x 32 halo patch is
+//     staged ONCE into LDS and re-read by all nine taps (this is what replaces im2col: the tap is
+//     a constant LDS row offset), and the nine [BN][32] weight slabs stream through a two-slot
+//     LDS ring, one barrier per tap; global loads for the next slab / next halo are in flight
+//     (registers) while the current tap's MFMAs run.
+//   * LDS rows are 32 bf16 + 16 B pad = 80 B, which makes every ds_read_b128 fragment read
+//     conflict-free (16 consecutive rows land on 16 distinct 16-B slots of the 256-B bank row).
+//   * v_mfma_f32_32x32x16_bf16, A = pixel fragment, B = cout fragment, so each lane ends up with
+//     one output channel (column) and 16 pixels (rows): per-channel BatchNorm partial sums are
+//     lane-local and cost one cross-half shuffle.
+//   * the input can come from two tensors (channels [0,c0) from x0, [c0,c0+c1) from x1): this is the
+//     decoder's torch.cat([skip, up], dim=1) (task_decoders.py:49) without materialising the cat.
+//
+// T = bf16: operands are staged as they are (throughput mode).
+// T = float ("split" mode): every fp32 operand is staged as hi = bf16(x), lo = bf16(x - hi) and each
+//   product is formed as hi*hi + hi*lo + lo*hi on the same MFMA path (about 2^-17 relative product
+//   error, fp32 accumulation).  This is the parity mode that is checked against the fp32 oracle.
+#include "common.h"
+#include <type_traits>
+
+struct Conv3x3Args {
+  const void* x0;
+  const void* x1;
+  const void* w;        // packed [9][nchunk][Cout][32]
+  const float* bias;    // [Cout] or null
+  void* y;
+  float* stat_part;     // [gridDim.x][2][Cout] or null
+  const float* ep_scale;  // optional epilogue affine (eval-mode BatchNorm folded), [Cout]
+  const float* ep_shift;
+  int ld0, c0, ld1, c1, ldy;
+  int B, H, W, Cout, tilesY, tilesX, nchunk;
+  int relu;
+};
+
+namespace {
+
+constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
+
+template <typename T> struct Piece;
+template <> struct Piece<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
+  }
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void to_lds(char* hi, char* /*lo*/, int off) const {
+    *reinterpret_cast<bf16x8*>(hi + off) = v;
+  }
+};
+template <> struct Piece<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = 0.f; b[i] = 0.f; }
+  }
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void to_lds(char* hi, char* lo, int off) const {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = (bf16_t)a[i];
+      l[i] = (bf16_t)(a[i] - (float)h[i]);
+      h[4 + i] = (bf16_t)b[i];
+      l[4 + i] = (bf16_t)(b[i] - (float)h[4 + i]);
+    }
+    *reinterpret_cast<bf16x8*>(hi + off) = h;
+    *reinterpret_cast<bf16x8*>(lo + off) = l;
+  }
+};
+
+template <typename T, int TH, int TW, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_mfma_kernel(Conv3x3Args a) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 2 : 1;
+  constexpr int HW_ = TW + 2, HH_ = TH + 2, HALO = HW_ * HH_;
+  constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  constexpr int A_PIECES = HALO * 4, A_IT = (A_PIECES + 255) / 256;
+  constexpr int B_PIECES = BN * 4, B_IT = (B_PIECES + 255) / 256;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;                               // [2][NIMG][A_BYTES]
+  char* const ldsB = smem + 2 * NIMG * A_BYTES;          // [2][NIMG][B_BYTES]
+
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+  const T* __restrict__ wp = static_cast<const T*>(a.w);
+  T* __restrict__ yout = static_cast<T*>(a.y);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  int bt = blockIdx.x;
+  const int tx = bt % a.tilesX; bt /= a.tilesX;
+  const int ty = bt % a.tilesY;
+  const int img = bt / a.tilesY;
+  const int y0 = ty * TH, x0p = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  const int ctot = a.c0 + a.c1;
+
+  // ---- per-thread staging coordinates (chunk independent) ----
+  int apix[A_IT];    // pixel index into the NHWC tensor, -1 = zero fill
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int idx = tid + i * 256;
+    const int px = idx >> 2, pc = idx & 3;
+    const int hy = px / HW_, hx = px - hy * HW_;
+    const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+    apix[i] = (idx < A_PIECES && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                  ? (img * a.H + gy) * a.W + gx : -1;
+  }
+  Piece<T> hreg[A_IT];
+  Piece<T> wreg[B_IT];
+
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int ch = c * 32 + ((tid + i * 256) & 3) * 8;
+      hreg[i].zero();
+      if (apix[i] >= 0) {
+        if (ch < a.c0) hreg[i].load(x0 + (long)apix[i] * a.ld0 + ch);
+        else if (ch < ctot) hreg[i].load(x1 + (long)apix[i] * a.ld1 + (ch - a.c0));
+      }
+    }
+  };
+  auto store_halo = [&](int buf) {
+    char* hi = ldsA + buf * NIMG * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < A_PIECES) hreg[i].to_lds(hi, hi + A_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
+    }
+  };
+  auto load_w = [&](int it) {
+    const int c = it / 9, tap = it - c * 9;
+    const T* base = wp + ((long)(tap * a.nchunk + c) * a.Cout) * 32;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 2, pc = idx & 3;
+      wreg[i].zero();
+      if (idx < B_PIECES && n0 + row < a.Cout) wreg[i].load(base + (long)(n0 + row) * 32 + pc * 8);
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* hi = ldsB + buf * NIMG * B_BYTES;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < B_PIECES) wreg[i].to_lds(hi, hi + B_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
+    }
+  };
+
+  // ---- fragment base offsets ----
+  int abase[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 32 + r;
+    const int py = m / TW, px = m - py * TW;
+    abase[mi] = (py * HW_ + px) * ROWB + h * 16;
+  }
+  int bbase[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bbase[ni] = (wn * WTN + ni * 32 + r) * ROWB + h * 16;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+
+  const int nit = a.nchunk * 9;
+
+  // ---- prologue ----
+  load_w(0);
+  load_halo(0);
+  store_w(0);
+  store_halo(0);
+  if (nit > 1) load_w(1);
+  __syncthreads();
+
+  for (int c = 0; c < a.nchunk; ++c) {
+    if (c + 1 < a.nchunk) load_halo(c + 1);
+    const char* Ahi = ldsA + (c & 1) * NIMG * A_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int it = c * 9 + tap;
+      const char* Bhi = ldsB + (it & 1) * NIMG * B_BYTES;
+      const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *reinterpret_cast<const bf16x8*>(Ahi + abase[mi] + tapoff + ks * 32);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          bfr[ni] = *reinterpret_cast<const bf16x8*>(Bhi + bbase[ni] + ks * 32);
+        if constexpr (SPLIT) {
+          bf16x8 al[MI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            al[mi] = *reinterpret_cast<const bf16x8*>(Ahi + A_BYTES + abase[mi] + tapoff + ks * 32);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            bl[ni] = *reinterpret_cast<const bf16x8*>(Bhi + B_BYTES + bbase[ni] + ks * 32);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+      // slot (it+1)&1 was last read by tap it-1, which every wave left at the previous barrier
+      if (it + 1 < nit) store_w((it + 1) & 1);
+      if (it + 2 < nit) load_w(it + 2);
+      if (tap == 8 && c + 1 < a.nchunk) store_halo((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias / folded affine / ReLU, store, per-channel partial statistics ----
+  float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN], LDS is free after the last barrier
+  const bool want_stats = a.stat_part != nullptr;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int nl = wn * WTN + ni * 32 + r;
+    const int n = n0 + nl;
+    const bool nok = n < a.Cout;
+    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+    const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
+    const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int m = wm * WTM + mi * 32 + row;
+        const int py = m / TW, px = m - py * TW;
+        const int gy = y0 + py, gx = x0p + px;
+        float v = acc[mi][ni][j] + bias;
+        if (a.ep_scale) v = v * esc + esh;
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (nok && gy < a.H && gx < a.W) {
+          yout[(((long)img * a.H + gy) * a.W + gx) * a.ldy + n] = from_f32<T>(v);
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (want_stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + nl] = s1;
+        red[(wm * 2 + 1) * BN + nl] = s2;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, nl = i - which * BN;
+      if (n0 + nl < a.Cout) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) s += red[(k * 2 + which) * BN + nl];
+        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = s;
+      }
+    }
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN>
+int launch_cfg(Conv3x3Args& a, hipStream_t s) {
+  constexpr int NIMG = std::is_same<T, float>::value ? 2 : 1;
+  constexpr int lds = 2 * NIMG * ((TH + 2) * (TW + 2) + BN) * ROWB;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  auto kern = conv3x3_mfma_kernel<T, TH, TW, BN, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+template <typename T>
+int dispatch(Conv3x3Args& a, hipStream_t s) {
+  const bool narrow = a.W <= 16;
+  if (a.Cout <= 64) {
+    if (narrow) return launch_cfg<T, 16, 16, 64, 4, 1>(a, s);
+    return launch_cfg<T, 8, 32, 64, 4, 1>(a, s);
+  }
+  if (narrow) return launch_cfg<T, 16, 16, 128, 2, 2>(a, s);
+  return launch_cfg<T, 8, 32, 128, 2, 2>(a, s);
+}
+
+}  // namespace
+
+// Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
+// (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.
+extern "C" int s2s_conv3x3_stat_blocks(int B, int H, int W, int Cout) {
+  (void)Cout;
+  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  if (W <= 16) return B * cdiv(H, 16) * cdiv(W, 16);
+  return B * cdiv(H, 8) * cdiv(W, 32);
+}
+
+extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                                const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                                const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W,
+                                int Cout, void* stream) {
+  if (!x0 || !w_packed || !y) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
+  if ((c0 % 8) || (c1 % 8) || (ld0 % 8) || (ld1 % 8) || (c1 > 0 && !x1)) return S2S_ERR_SHAPE;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return S2S_ERR_NULL;
+  const uintptr_t al = dtype == S2S_BF16 ? 15 : 15;
+  if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al)) return S2S_ERR_ALIGN;
+  Conv3x3Args a;
+  a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift;
+  a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
+  a.tilesX = a.tilesY = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == S2S_BF16) return dispatch<bf16_t>(a, s);
+  if (dtype == S2S_F32) return dispatch<float>(a, s);
+  return S2S_ERR_DTYPE;
+}

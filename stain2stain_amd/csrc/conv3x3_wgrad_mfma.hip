@@ -1,0 +1,291 @@
+// Weight gradient of the 3x3 / pad 1 convolution, NHWC activations, MFMA (gfx950).
+//
+// Replaces autograd's conv2d weight-gradient for the reference's DoubleConv layers
+// (src/models/components/shared_encoder.py:15,18; task_decoders.py:15,18).
+//
+//   dW[tap][co][ci] = sum_{pixel} dY[pixel][co] * X[pixel (+) tap][ci]
+//
+// As a GEMM the reduction index is the PIXEL, which is the slow axis of both NHWC operands, so the
+// MFMA fragments (8 consecutive k per lane) are columns of the staged LDS images.  They are read
+// with ds_read_b64_tr_b16 (CDNA4 transposed LDS read): the images stay [pixel][32 channels]
+// (64-B rows, which also makes the transposed reads bank-conflict free: 4 rows x 2 column groups
+// of one half-wave cover the 256-B bank row exactly once), and the tap is a constant row offset
+// into the (TH+2)x(TW+2) halo image, so one staged halo serves all nine taps.
+//
+//   * workgroup = 4 waves = 64 co x 64 ci x 9 taps; each wave owns a 32x32 (co,ci) block for all
+//     nine taps (9 x 16 accumulator registers), so a dY fragment is read once per 9 MFMAs.
+//   * split-K over pixel tiles: blockIdx.z walks tiles z, z+S, ...; partial sums go to
+//     part[S][9][Cout][Cin] (fp32) and s2s_conv3x3_wgrad_reduce folds them, deterministically, into
+//     the OIHW fp32 gradient the optimiser sees.
+//   * T = float: hi/lo bf16 split of both operands, 3 MFMAs per product (see conv3x3_mfma.hip).
+#include "common.h"
+#include <type_traits>
+
+struct WgradArgs {
+  const void* dy;
+  const void* x0;
+  const void* x1;
+  float* part;
+  int lddy, Cout, ld0, c0, ld1, c1;
+  int B, H, W, tilesY, tilesX, ntiles, S;
+};
+
+namespace {
+
+template <typename T> struct WPiece;
+template <> struct WPiece<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
+  }
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void to_lds(char* hi, char*, int off) const { *reinterpret_cast<bf16x8*>(hi + off) = v; }
+};
+template <> struct WPiece<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = 0.f; b[i] = 0.f; }
+  }
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void to_lds(char* hi, char* lo, int off) const {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = (bf16_t)a[i];
+      l[i] = (bf16_t)(a[i] - (float)h[i]);
+      h[4 + i] = (bf16_t)b[i];
+      l[4 + i] = (bf16_t)(b[i] - (float)h[4 + i]);
+    }
+    *reinterpret_cast<bf16x8*>(hi + off) = h;
+    *reinterpret_cast<bf16x8*>(lo + off) = l;
+  }
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// 8 consecutive-k elements of one column: two transposed 4x16 block reads (rows +0..3, +4..7)
+__device__ __forceinline__ bf16x8 tr_frag(const char* p_rows0, int row_stride4) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_rows0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_rows0 + row_stride4));
+  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = l4[i]; r[4 + i] = h4[i]; }
+  return r;
+}
+
+template <typename T, int TH, int TW>
+__global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 2 : 1;
+  constexpr int NPX = TH * TW;                 // 128
+  constexpr int HW_ = TW + 2, HALO = (TH + 2) * HW_;
+  constexpr int DY_BYTES = 2 * NPX * 64;       // two 32-channel images
+  constexpr int X_BYTES = 2 * HALO * 64;
+  constexpr int DY_PIECES = NPX * 8, DY_IT = (DY_PIECES + 255) / 256;
+  constexpr int X_PIECES = HALO * 8, X_IT = (X_PIECES + 255) / 256;
+  constexpr int KSTEPS = NPX / 16;
+  static_assert(TW % 16 == 0, "a k-step is 16 consecutive pixels of one tile row");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsDY = smem;                          // [NIMG][2][NPX][64B]
+  char* const ldsX = smem + NIMG * DY_BYTES;         // [NIMG][2][HALO][64B]
+
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0 + a.c1;
+
+  // transposed-read lane geometry (see header comment)
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;  // bytes, k-row 0 of the step
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  WPiece<T> dreg[DY_IT];
+  WPiece<T> xreg[X_IT];
+
+  auto load_tile = [&](int tile) {
+    int bt = tile;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int img = bt / a.tilesY;
+    const int y0 = ty * TH, xs = tx * TW;
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      const int py = px / TW, pxx = px - py * TW;
+      const int gy = y0 + py, gx = xs + pxx, co = co0 + pc * 8;
+      dreg[i].zero();
+      if (idx < DY_PIECES && gy < a.H && gx < a.W && co < a.Cout)
+        dreg[i].load(dy + ((long)(img * a.H + gy) * a.W + gx) * a.lddy + co);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      const int hy = px / HW_, hx = px - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = xs - 1 + hx, ci = ci0 + pc * 8;
+      xreg[i].zero();
+      if (idx < X_PIECES && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const long pix = (long)(img * a.H + gy) * a.W + gx;
+        if (ci < a.c0) xreg[i].load(x0 + pix * a.ld0 + ci);
+        else if (ci < cin) xreg[i].load(x1 + pix * a.ld1 + (ci - a.c0));
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      if (idx < DY_PIECES)
+        dreg[i].to_lds(ldsDY, ldsDY + DY_BYTES, (pc >> 2) * (NPX * 64) + px * 64 + (pc & 3) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      if (idx < X_PIECES)
+        xreg[i].to_lds(ldsX, ldsX + X_BYTES, (pc >> 2) * (HALO * 64) + px * 64 + (pc & 3) * 16);
+    }
+  };
+
+  const char* const Ahi = ldsDY + wco * (NPX * 64) + frag_off;
+  const char* const Bhi = ldsX + wci * (HALO * 64) + frag_off;
+
+  int tile = blockIdx.z;
+  if (tile < a.ntiles) load_tile(tile);
+  for (; tile < a.ntiles; tile += a.S) {
+    __syncthreads();  // everyone is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (tile + a.S < a.ntiles) load_tile(tile + a.S);  // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+      bf16x8 al;
+      if constexpr (SPLIT) al = tr_frag(Ahi + DY_BYTES + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hoff = ((py + tap / 3) * HW_ + px + tap % 3) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        if constexpr (SPLIT) {
+          const bf16x8 bl = tr_frag(Bhi + X_BYTES + hoff, 4 * 64);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr, acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bl, acc[tap], 0, 0, 0);
+        }
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial slab: part[z][tap][co][ci] ----
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (co < a.Cout && ci < cin)
+        a.part[(((long)blockIdx.z * 9 + tap) * a.Cout + co) * cin + ci] = acc[tap][j];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
+                                    int Cin, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (co, ci)
+  const long n = (long)Cout * Cin;
+  if (i >= n) return;
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int z = 0; z < S; ++z)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] += part[((long)z * 9 + t) * n + i];
+  float* g = grad + i * 9;  // OIHW: [co][ci][kh][kw]
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = accumulate ? g[t] + s[t] : s[t];
+}
+
+template <typename T, int TH, int TW>
+int launch_wgrad(WgradArgs& a, hipStream_t s) {
+  constexpr int NIMG = std::is_same<T, float>::value ? 2 : 1;
+  constexpr int lds = NIMG * (2 * TH * TW * 64 + 2 * (TH + 2) * (TW + 2) * 64);
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  a.ntiles = a.B * a.tilesY * a.tilesX;
+  if (a.S > a.ntiles) return S2S_ERR_SHAPE;
+  auto kern = conv3x3_wgrad_kernel<T, TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// one pixel tile = 8 rows x 16 columns (halo 10 x 18); this shape keeps the staging prefetch small
+// enough for two workgroups per CU (a 4 x 32 tile spills at that occupancy)
+int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
+
+}  // namespace
+
+// Split count the kernel will use for this problem; the caller sizes `part` as
+// [splits][9][Cout][Cin] floats.
+extern "C" int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
+  const int nt = wgrad_ntiles(B, H, W);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
+  int s = cdiv(768, mn);
+  if (s > nt) s = nt;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
+                                      const void* x1, int ld1, int c1, float* part, float* grad_oihw,
+                                      int accumulate, int B, int H, int W, void* stream) {
+  if (!dy || !x0 || !part || !grad_oihw) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
+  if ((Cout % 8) || (c0 % 8) || (c1 % 8) || (lddy % 8) || (ld0 % 8) || (ld1 % 8) || (c1 > 0 && !x1)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x0 & 15) || ((uintptr_t)x1 & 15)) return S2S_ERR_ALIGN;
+  WgradArgs a;
+  a.dy = dy; a.x0 = x0; a.x1 = x1; a.part = part;
+  a.lddy = lddy; a.Cout = Cout; a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
+  a.B = B; a.H = H; a.W = W;
+  a.S = s2s_conv3x3_wgrad_splits(B, H, W, c0 + c1, Cout);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
+  else if (dtype == S2S_F32) rc = launch_wgrad<float, 8, 16>(a, s);
+  else return S2S_ERR_DTYPE;
+  if (rc != S2S_OK) return rc;
+  const long n = (long)Cout * (c0 + c1);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad_oihw, a.S,
+                     Cout, c0 + c1, accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

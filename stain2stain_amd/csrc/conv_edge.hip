@@ -1,0 +1,390 @@
+// The two bandwidth-bound convolutions at the ends of the U-Net.
+//
+//   * stem: Conv3x3(pad 1) from the image tensor (NCHW fp32, Cin <= 8; 3 for RGB tiles) to NHWC
+//     features -- the first conv of SharedEncoder.inc (src/models/components/shared_encoder.py:15,67).
+//     K = 9*Cin = 27 is too thin for an MFMA tile and the layer is bound by writing the output, so it is
+//     a direct VALU convolution: one thread per output pixel, weights broadcast from LDS, the 3x3xCin
+//     patch in registers, 16 output channels at a time; it also emits the BatchNorm partial sums.
+//   * head: Conv1x1 from NHWC features to the NCHW fp32 velocity field -- FlowMatchingDecoder.outc
+//     (src/models/components/task_decoders.py:100,132), Cout <= 4.
+// and their backward passes (weight / bias gradients; the stem needs no data gradient).
+#include "common.h"
+
+namespace {
+
+constexpr int STEM_MAX_CIN = 8;
+
+// ---------------------------------------------------------------------------------------------
+// stem forward
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y, int ldy,
+                                                       float* __restrict__ stat_part, int B, int H, int W, int Cin,
+                                                       int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);            // [Cout][Cin*9]
+  float* red = wl + Cout * Cin * 9;                      // [4 waves][2][Cout]
+  const int K = Cin * 9;
+  for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const long npix = (long)B * H * W;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = p < npix;
+  const int px = ok ? (int)(p % W) : 0;
+  const int py = ok ? (int)((p / W) % H) : 0;
+  const int n = ok ? (int)(p / ((long)W * H)) : 0;
+  float patch[STEM_MAX_CIN * 9];
+#pragma unroll
+  for (int ci = 0; ci < STEM_MAX_CIN; ++ci)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      patch[ci * 9 + t] = (ok && ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                              ? x[(((long)n * Cin + ci) * H + yy) * W + xx] : 0.f;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < Cout; c0 += 8) {
+    f32x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float acc = 0.f;
+      const float* wr = wl + (c0 + k) * K;
+#pragma unroll
+      for (int ci = 0; ci < STEM_MAX_CIN; ++ci)
+        if (ci < Cin)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc = fmaf(patch[ci * 9 + t], wr[ci * 9 + t], acc);
+      o.v[k] = acc + (bias ? bias[c0 + k] : 0.f);
+    }
+    if (ok) store8(y + p * ldy + c0, o);
+    if (stat_part) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = ok ? o.v[k] : 0.f;
+        const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+        if (lane == 0) { red[(wave * 2 + 0) * Cout + c0 + k] = s1; red[(wave * 2 + 1) * Cout + c0 + k] = s2; }
+      }
+    }
+  }
+  if (stat_part) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
+      const int which = i / Cout, c = i - which * Cout;
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += red[(k * 2 + which) * Cout + c];
+      stat_part[((long)blockIdx.x * 2 + which) * Cout + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem weight / bias gradient:  dW[co][ci][tap] = sum_p dY[p][co] * x[p (+) tap][ci],  db[co] = sum_p dY[p][co]
+// One workgroup walks 8x16 pixel tiles; thread = (co mod 64, column group); dY through LDS, the
+// image halo through LDS (broadcast reads).  part[gridDim.x][Cout][Cin*9+1].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ dy, int lddy,
+                                                         const float* __restrict__ x, float* __restrict__ part,
+                                                         int B, int H, int W, int Cin, int Cout, int tilesY,
+                                                         int tilesX) {
+  __shared__ float dyl[128][65];                        // [pixel][co] (+1 pad)
+  __shared__ float xl[STEM_MAX_CIN][10][18];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int K = Cin * 9 + 1;                             // +1: bias column
+  const int kper = (K + 3) / 4;                          // columns per thread group
+  const int k_begin = grp * kper;
+  const int ntiles = B * tilesY * tilesX;
+  for (int cb = 0; cb < Cout; cb += 64) {
+    float acc[(STEM_MAX_CIN * 9 + 1 + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) acc[i] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      int bt = tile;
+      const int tx = bt % tilesX; bt /= tilesX;
+      const int ty = bt % tilesY;
+      const int n = bt / tilesY;
+      const int y0 = ty * 8, x0 = tx * 16;
+      __syncthreads();
+      for (int i = threadIdx.x; i < 128 * 64; i += 256) {
+        const int pp = i >> 6, c = i & 63;
+        const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+        dyl[pp][c] = (gy < H && gx < W && cb + c < Cout)
+                         ? to_f32(dy[(((long)n * H + gy) * W + gx) * lddy + cb + c]) : 0.f;
+      }
+      for (int i = threadIdx.x; i < Cin * 10 * 18; i += 256) {
+        const int ci = i / 180, r = i - ci * 180, hy = r / 18, hx = r - hy * 18;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        xl[ci][hy][hx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((long)n * Cin + ci) * H + gy) * W + gx] : 0.f;
+      }
+      __syncthreads();
+      for (int pp = 0; pp < 128; ++pp) {
+        const float g = dyl[pp][col];
+        const int py = pp >> 4, px = pp & 15;
+#pragma unroll
+        for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) {
+          const int k = k_begin + i;
+          if (i < kper && k < K) {
+            float xv = 1.f;
+            if (k < K - 1) {
+              const int ci = k / 9, t = k - ci * 9;
+              xv = xl[ci][py + t / 3][px + t % 3];
+            }
+            acc[i] = fmaf(g, xv, acc[i]);
+          }
+        }
+      }
+    }
+    if (cb + col < Cout) {
+#pragma unroll
+      for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) {
+        const int k = k_begin + i;
+        if (i < kper && k < K) part[((long)blockIdx.x * Cout + cb + col) * K + k] = acc[i];
+      }
+    }
+  }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int Cin, float* dw, float* db,
+                                         int accumulate) {
+  const int K = Cin * 9 + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * K) return;
+  const int co = i / K, k = i - co * K;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * Cout * K + i];
+  float* dst = (k < K - 1) ? dw + co * (K - 1) + k : db + co;
+  if (k == K - 1 && !db) return;
+  *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: 1x1 conv NHWC -> NCHW fp32
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_COUT = 4;
+
+template <typename T>
+__global__ void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                const float* __restrict__ bias, float* __restrict__ y, long npix, int HW, int C,
+                                int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);  // [Cout][C]
+  for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    float acc[HEAD_MAX_COUT];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_COUT; ++o) acc[o] = 0.f;
+    for (int c8 = 0; c8 < C; c8 += 8) {
+      const f32x8 v = load8(x + p * ldx + c8);
+#pragma unroll
+      for (int o = 0; o < HEAD_MAX_COUT; ++o)
+        if (o < Cout)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[o] = fmaf(v.v[k], wl[o * C + c8 + k], acc[o]);
+    }
+    const long n = p / HW, q = p - n * HW;
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_COUT; ++o)
+      if (o < Cout) y[(n * Cout + o) * HW + q] = acc[o] + (bias ? bias[o] : 0.f);
+  }
+}
+
+// dX[p][c] = sum_o dY[n][o][q] * W[o][c]
+template <typename T>
+__global__ void head_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                     int lddx, long npix, int HW, int C, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);
+  for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long n = p / HW, q = p - n * HW;
+    float g[HEAD_MAX_COUT];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_COUT; ++o) g[o] = o < Cout ? dy[(n * Cout + o) * HW + q] : 0.f;
+    for (int c8 = 0; c8 < C; c8 += 8) {
+      f32x8 v;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_COUT; ++o)
+          if (o < Cout) a = fmaf(g[o], wl[o * C + c8 + k], a);
+        v.v[k] = a;
+      }
+      store8(dx + p * lddx + c8, v);
+    }
+  }
+}
+
+// dW[o][c] = sum_p dY[p][o]*X[p][c], db[o] = sum_p dY[p][o]; part[gridDim.x][Cout][C+1]
+template <typename T>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x,
+                                                         int ldx, float* __restrict__ part, long npix, int HW, int C,
+                                                         int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xl = reinterpret_cast<float*>(smem);            // [64 px][C+1]
+  float* gl = xl + 64 * (C + 1);                         // [64 px][HEAD_MAX_COUT]
+  const int nout = Cout * (C + 1);
+  float acc[8];                                          // outputs tid, tid+256, ... (nout <= 2048)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (long p0 = (long)blockIdx.x * 64; p0 < npix; p0 += (long)gridDim.x * 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * C; i += 256) {
+      const int pp = i / C, c = i - pp * C;
+      xl[pp * (C + 1) + c] = (p0 + pp < npix) ? to_f32(x[(p0 + pp) * ldx + c]) : 0.f;
+    }
+    for (int i = threadIdx.x; i < 64 * HEAD_MAX_COUT; i += 256) {
+      const int pp = i / HEAD_MAX_COUT, o = i - pp * HEAD_MAX_COUT;
+      float v = 0.f;
+      if (o < Cout && p0 + pp < npix) {
+        const long p = p0 + pp, n = p / HW, q = p - n * HW;
+        v = dy[(n * Cout + o) * HW + q];
+      }
+      gl[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < nout) {
+        const int o = id / (C + 1), c = id - o * (C + 1);
+        float a = acc[i];
+        if (c < C) for (int pp = 0; pp < 64; ++pp) a = fmaf(gl[pp * HEAD_MAX_COUT + o], xl[pp * (C + 1) + c], a);
+        else for (int pp = 0; pp < 64; ++pp) a += gl[pp * HEAD_MAX_COUT + o];
+        acc[i] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = threadIdx.x + i * 256;
+    if (id < nout) part[(long)blockIdx.x * nout + id] = acc[i];
+  }
+}
+
+__global__ void head_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int C, float* dw, float* db,
+                                         int accumulate) {
+  const int nout = Cout * (C + 1);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nout) return;
+  const int o = i / (C + 1), c = i - o * (C + 1);
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * nout + i];
+  if (c == C && !db) return;
+  float* dst = (c < C) ? dw + o * C + c : db + o;
+  *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+}  // namespace
+
+extern "C" int s2s_stem_stat_blocks(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  return (int)(((long)B * H * W + 255) / 256);
+}
+
+extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y,
+                                    int ldy, float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x_nchw || !w_oihw || !y) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > STEM_MAX_CIN || Cout <= 0 || (Cout % 8) || (ldy % 8))
+    return S2S_ERR_SHAPE;
+  const int lds = (Cout * Cin * 9 + 8 * Cout) * 4;
+  if (lds > 64 * 1024) return S2S_ERR_SHAPE;
+  const int grid = s2s_stem_stat_blocks(B, H, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, x_nchw, w_oihw, bias, (bf16_t*)y, ldy,
+                       stat_part, B, H, W, Cin, Cout);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, x_nchw, w_oihw, bias, (float*)y, ldy,
+                       stat_part, B, H, W, Cin, Cout);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  const int nt = B * cdiv(H, 8) * cdiv(W, 16);
+  return nt < 1024 ? nt : 1024;
+}
+
+// part: float[blocks][Cout][Cin*9+1]
+extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part,
+                                      float* dw_oihw, float* dbias, int accumulate, int B, int H, int W, int Cin,
+                                      int Cout, void* stream) {
+  if (!dy || !x_nchw || !part || !dw_oihw) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > STEM_MAX_CIN || Cout <= 0 || (Cout % 8) || (lddy % 8))
+    return S2S_ERR_SHAPE;
+  const int nb = s2s_stem_wgrad_blocks(B, H, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dy, lddy, x_nchw, part, B,
+                       H, W, Cin, Cout, cdiv(H, 8), cdiv(W, 16));
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dy, lddy, x_nchw, part, B, H,
+                       W, Cin, Cout, cdiv(H, 8), cdiv(W, 16));
+  else return S2S_ERR_DTYPE;
+  const int n = Cout * (Cin * 9 + 1);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, part, nb, Cout, Cin, dw_oihw,
+                     dbias, accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias,
+                                    float* y_nchw, int B, int H, int W, int C, int Cout, void* stream) {
+  if (!x || !w || !y_nchw) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || Cout <= 0 || Cout > HEAD_MAX_COUT)
+    return S2S_ERR_SHAPE;
+  const long npix = (long)B * H * W;
+  long grid = (npix + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((int)grid), dim3(256), Cout * C * 4, s, (const bf16_t*)x, ldx, w,
+                       bias, y_nchw, npix, H * W, C, Cout);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((int)grid), dim3(256), Cout * C * 4, s, (const float*)x, ldx, w,
+                       bias, y_nchw, npix, H * W, C, Cout);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_head_wgrad_blocks(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  const long nb = ((long)B * H * W + 63) / 64;
+  return (int)(nb < 1024 ? nb : 1024);
+}
+
+// part: float[blocks][Cout][C+1]
+extern "C" int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void* x, int ldx, const float* w, void* dx,
+                                    int lddx, float* part, float* dw, float* dbias, int accumulate, int B, int H, int W,
+                                    int C, int Cout, void* stream) {
+  if (!dy_nchw || !x || !w || !dx || !part || !dw) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) || Cout <= 0 || Cout > HEAD_MAX_COUT)
+    return S2S_ERR_SHAPE;
+  if (Cout * (C + 1) > 2048) return S2S_ERR_SHAPE;
+  const long npix = (long)B * H * W;
+  long grid = (npix + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  const int nb = s2s_head_wgrad_blocks(B, H, W);
+  const int lds = (64 * (C + 1) + 64 * HEAD_MAX_COUT) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define S2S_HEAD_BWD(TT)                                                                                         \
+  hipLaunchKernelGGL(head_bwd_data_kernel<TT>, dim3((int)grid), dim3(256), Cout * C * 4, s, dy_nchw, w, (TT*)dx, \
+                     lddx, npix, H * W, C, Cout);                                                                \
+  hipLaunchKernelGGL(head_wgrad_kernel<TT>, dim3(nb), dim3(256), lds, s, dy_nchw, (const TT*)x, ldx, part, npix, \
+                     H * W, C, Cout);
+  if (dtype == S2S_BF16) { S2S_HEAD_BWD(bf16_t) }
+  else if (dtype == S2S_F32) { S2S_HEAD_BWD(float) }
+  else return S2S_ERR_DTYPE;
+#undef S2S_HEAD_BWD
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 256)), dim3(256), 0, s, part, nb, Cout, C,
+                     dw, dbias, accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

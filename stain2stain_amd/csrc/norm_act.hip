@@ -1,0 +1,442 @@
+// BatchNorm2d (training / eval) + ReLU (+ MaxPool2d(2)) around the convolutions, NHWC, HBM-bound.
+//
+// Replaces nn.BatchNorm2d -> nn.ReLU(inplace) (-> nn.MaxPool2d(2) of the next Down block) of the
+// reference's DoubleConv / Down (src/models/components/shared_encoder.py:16-20,32-37;
+// task_decoders.py:16-20) and their autograd backward.
+//
+//   forward : conv epilogue leaves per-row-block partial (sum, sum^2) -> s2s_bn_finalize
+//             (mean, 1/std, folded scale/shift, running-stat update) -> s2s_bn_relu_apply
+//             (one pass: y = relu(x*scale+shift), optionally also the 2x2 max-pooled y)
+//   backward: s2s_bn_relu_bwd_reduce (sum dz, sum dz*xhat; dz = g*(y>0); g may include the
+//             max-pool scatter of the next level's gradient, recomputed from y) ->
+//             s2s_bn_bwd_finalize -> s2s_bn_relu_bwd_apply (dx, + partial sum of dx = conv-bias grad)
+//
+// All tensors are [B][H][W][C] views with an explicit pixel stride ("ld", in elements) so that a
+// channel slice of a wider buffer (the decoder's concat buffer) can be read or written in place.
+// Every thread moves 16-B (bf16) / 32-B (fp32) pieces: 8 consecutive channels of one pixel.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_ROWS = 8;  // pixel groups per workgroup in the reduction kernels (256 = 32 x 8)
+
+// ---------------------------------------------------------------------------------------------
+// statistics finalize
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long* num_batches, float momentum,
+                                   float eps, float* mean_out, float* invstd_out, float* scale_out,
+                                   float* shift_out) {
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int i = rg; i < nblk; i += 8) {
+      a += (double)part[((long)i * 2 + 0) * C + c];
+      b += (double)part[((long)i * 2 + 1) * C + c];
+    }
+  s1[rg][cl] = a;
+  s2[rg][cl] = b;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = beta[c] - (float)mean * sc;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+}
+
+__global__ void bn_eval_prepare_kernel(int C, const float* gamma, const float* beta, const float* rmean,
+                                       const float* rvar, float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward apply (+ optional fused 2x2 max pool)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_relu_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, T* __restrict__ y, int ldy,
+                                     T* __restrict__ pool, int ldp, int B, int H, int W, int C) {
+  const int cp = C >> 3;
+  const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+  const long total = (long)B * Hw * Ww * cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cp) * 8;
+    long t = i / cp;
+    const int wx = (int)(t % Ww); t /= Ww;
+    const int wy = (int)(t % Hw);
+    const int n = (int)(t / Hw);
+    float sc[8], sh[8], mx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 + k]; sh[k] = shift[c8 + k]; mx[k] = 0.f; }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = wy * 2 + dy, xx = wx * 2 + dx;
+        if (yy < H && xx < W) {
+          const long pix = ((long)n * H + yy) * W + xx;
+          f32x8 v = load8(x + pix * ldx + c8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            v.v[k] = fmaxf(v.v[k] * sc[k] + sh[k], 0.f);
+            // pool on the value as stored (bf16-rounded in bf16 mode) so backward can recompute argmax
+            const float st = to_f32(from_f32<T>(v.v[k]));
+            mx[k] = fmaxf(mx[k], st);
+          }
+          store8(y + pix * ldy + c8, v);
+        }
+      }
+    if (pool && wy < Hp && wx < Wp) {
+      f32x8 m;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m.v[k] = mx[k];
+      store8(pool + (((long)n * Hp + wy) * Wp + wx) * ldp + c8, m);
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ x, int ldx, T* __restrict__ pool, int ldp, int B, int H,
+                                int W, int C) {
+  const int cp = C >> 3, Hp = H >> 1, Wp = W >> 1;
+  const long total = (long)B * Hp * Wp * cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cp) * 8;
+    long t = i / cp;
+    const int wx = (int)(t % Wp); t /= Wp;
+    const int wy = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    f32x8 m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m.v[k] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long pix = ((long)n * H + wy * 2 + dy) * W + wx * 2 + dx;
+        const f32x8 v = load8(x + pix * ldx + c8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m.v[k] = fmaxf(m.v[k], v.v[k]);
+      }
+    store8(pool + (((long)n * Hp + wy) * Wp + wx) * ldp + c8, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// Gradient reaching the ReLU output at the 4 pixels of one 2x2 window, 8 channels:
+//   g = g1 (optional dense / sliced gradient) + max-pool scatter of gp (optional).
+// The pool winner is the FIRST maximum in (0,0),(0,1),(1,0),(1,1) order, as ATen's max_pool2d picks
+// it; ties at 0 are irrelevant because the ReLU mask kills them.
+template <typename T>
+struct WindowGrad {
+  float dz[4][8];    // g * (y > 0)
+  float xh[4][8];    // normalised conv output
+  bool ok[4];
+  __device__ __forceinline__ void load(const T* __restrict__ g1, int ldg1, const T* __restrict__ gp, int ldgp,
+                                       const T* __restrict__ y, int ldy, const T* __restrict__ x, int ldx,
+                                       const float* mean, const float* invstd, int n, int wy, int wx, int H,
+                                       int W, int c8) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    float yv[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = wy * 2 + (q >> 1), xx = wx * 2 + (q & 1);
+      ok[q] = yy < H && xx < W;
+      if (ok[q]) {
+        const long pix = ((long)n * H + yy) * W + xx;
+        const f32x8 a = load8(y + pix * ldy + c8);
+        const f32x8 b = load8(x + pix * ldx + c8);
+        f32x8 g;
+        if (g1) g = load8(g1 + pix * ldg1 + c8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          yv[q][k] = a.v[k];
+          xh[q][k] = (b.v[k] - mean[c8 + k]) * invstd[c8 + k];
+          dz[q][k] = g1 ? g.v[k] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { yv[q][k] = 0.f; xh[q][k] = 0.f; dz[q][k] = 0.f; }
+      }
+    }
+    if (gp && wy < Hp && wx < Wp) {
+      const f32x8 p = load8(gp + (((long)n * Hp + wy) * Wp + wx) * ldgp + c8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int best = 0;
+        float bv = yv[0][k];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (yv[q][k] > bv) { bv = yv[q][k]; best = q; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q == best) dz[q][k] += p.v[k];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (!(yv[q][k] > 0.f)) dz[q][k] = 0.f;
+  }
+};
+
+// partial[blk][2][C]: sum dz, sum dz*xhat.  grid = (C/32 rounded up, nblk); 256 threads = 4 channel
+// pieces x 64 window groups.
+template <typename T>
+__global__ void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+                                          const T* x, int ldx, const float* mean, const float* invstd,
+                                          float* part, int B, int H, int W, int C) {
+  const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;
+  const long nwin = (long)B * Hw * Ww;
+  const int pc = threadIdx.x & 3, wl = threadIdx.x >> 2;   // 4 pieces (32 channels) x 64 windows
+  const int c8 = blockIdx.x * 32 + pc * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (c8 < C) {
+    for (long w = (long)blockIdx.y * 64 + wl; w < nwin; w += (long)gridDim.y * 64) {
+      long t = w;
+      const int wx = (int)(t % Ww); t /= Ww;
+      const int wy = (int)(t % Hw);
+      const int n = (int)(t / Hw);
+      WindowGrad<T> wg;
+      wg.load(g1, ldg1, gp, ldgp, y, ldy, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] += wg.dz[q][k]; s2[k] += wg.dz[q][k] * wg.xh[q][k]; }
+    }
+  }
+  __shared__ float red[2][64][33];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][wl][pc * 8 + k] = s1[k]; red[1][wl][pc * 8 + k] = s2[k]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5, cl = threadIdx.x & 31;
+    float s = 0.f;
+    for (int r = 0; r < 64; ++r) s += red[which][r][cl];
+    const int c = blockIdx.x * 32 + cl;
+    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = s;
+  }
+}
+
+// sums partial[nblk][2][C] -> dgamma, dbeta (accumulate optional) and the two per-channel means
+__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
+                                       float* dbeta, int accumulate, float* c1, float* c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    a += (double)part[((long)i * 2 + 0) * C + c];
+    b += (double)part[((long)i * 2 + 1) * C + c];
+  }
+  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  c1[c] = (float)(a / count);
+  c2[c] = (float)(b / count);
+}
+
+// dx = gamma*invstd*(dz - c1 - xhat*c2); optional partial sums of dx over pixels (conv-bias gradient)
+template <typename T>
+__global__ void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+                                         const T* x, int ldx, const float* mean, const float* invstd,
+                                         const float* gamma, const float* c1, const float* c2, T* dx, int lddx,
+                                         float* dxsum_part, int B, int H, int W, int C) {
+  const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;
+  const long nwin = (long)B * Hw * Ww;
+  const int pc = threadIdx.x & 3, wl = threadIdx.x >> 2;
+  const int c8 = blockIdx.x * 32 + pc * 8;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  if (c8 < C) {
+    float ga[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ga[k] = gamma[c8 + k] * invstd[c8 + k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k]; }
+    for (long w = (long)blockIdx.y * 64 + wl; w < nwin; w += (long)gridDim.y * 64) {
+      long t = w;
+      const int wx = (int)(t % Ww); t /= Ww;
+      const int wy = (int)(t % Hw);
+      const int n = (int)(t / Hw);
+      WindowGrad<T> wg;
+      wg.load(g1, ldg1, gp, ldgp, y, ldy, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!wg.ok[q]) continue;
+        const long pix = ((long)n * H + wy * 2 + (q >> 1)) * W + wx * 2 + (q & 1);
+        f32x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o.v[k] = ga[k] * (wg.dz[q][k] - k1[k] - wg.xh[q][k] * k2[k]);
+          s[k] += o.v[k];
+        }
+        store8(dx + pix * lddx + c8, o);
+      }
+    }
+  }
+  if (dxsum_part) {
+    __shared__ float red[64][33];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wl][pc * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float t = 0.f;
+      for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
+      const int c = blockIdx.x * 32 + threadIdx.x;
+      if (c < C) dxsum_part[(long)blockIdx.y * C + c] = t;
+    }
+  }
+}
+
+// out[c] (+)= sum_i part[i][c]
+__global__ void colsum_finalize_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int i = 0; i < nblk; ++i) a += (double)part[(long)i * C + c];
+  out[c] = accumulate ? out[c] + (float)a : (float)a;
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  if (b > 2048 * 4) b = 2048 * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline int red_blocks(int B, int H, int W, int C) {
+  const long nwin = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  long want = 2048 / cdiv(C, 32);
+  if (want < 1) want = 1;
+  long nb = (nwin + 63) / 64;
+  if (nb > want) nb = want;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+}  // namespace
+
+extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, long* num_batches,
+                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                               void* stream) {
+  if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift) return S2S_ERR_NULL;
+  if (nblk <= 0 || C <= 0 || count <= 0) return S2S_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
+                     (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
+                     invstd, scale, shift);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* rmean,
+                                   const float* rvar, float eps, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !rmean || !rvar || !scale || !shift) return S2S_ERR_NULL;
+  if (C <= 0) return S2S_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                     rmean, rvar, eps, scale, shift);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_bn_relu_apply(int dtype, const void* x, int ldx, const float* scale, const float* shift, void* y,
+                                 int ldy, void* pool, int ldp, int B, int H, int W, int C, void* stream) {
+  if (!x || !scale || !shift || !y) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8) || (pool && (ldp % 8)))
+    return S2S_ERR_SHAPE;
+  const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(bn_relu_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       scale, shift, (bf16_t*)y, ldy, (bf16_t*)pool, ldp, B, H, W, C);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, ldx,
+                       scale, shift, (float*)y, ldy, (float*)pool, ldp, B, H, W, C);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_maxpool2(int dtype, const void* x, int ldx, void* pool, int ldp, int B, int H, int W, int C,
+                            void* stream) {
+  if (!x || !pool) return S2S_ERR_NULL;
+  if (B <= 0 || H < 2 || W < 2 || C <= 0 || (C % 8) || (ldx % 8) || (ldp % 8)) return S2S_ERR_SHAPE;
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       (bf16_t*)pool, ldp, B, H, W, C);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, ldx,
+                       (float*)pool, ldp, B, H, W, C);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// number of partial rows s2s_bn_relu_bwd needs in each of its two workspaces
+extern "C" int s2s_bn_bwd_blocks(int B, int H, int W, int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return S2S_ERR_SHAPE;
+  return red_blocks(B, H, W, C);
+}
+
+// Whole BN+ReLU(+pool scatter) backward: reduce -> finalize -> apply (-> conv-bias gradient).
+//   g1/gp : gradient wrt the ReLU output (dense or channel slice) / wrt the pooled output (may be null)
+//   y, x  : saved ReLU output and conv output;  work: float[2*blocks*2*C + 2*C]
+extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const void* y, int ldy,
+                               const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
+                               float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx,
+                               float* work, int B, int H, int W, int C, void* stream) {
+  if ((!g1 && !gp) || !y || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx || !work) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldy % 8) || (ldx % 8) || (lddx % 8) ||
+      (g1 && (ldg1 % 8)) || (gp && (ldgp % 8)))
+    return S2S_ERR_SHAPE;
+  const int nb = red_blocks(B, H, W, C);
+  float* part = work;                       // [nb][2][C]
+  float* part2 = work + (long)nb * 2 * C;   // [nb][C]
+  float* c1 = part2 + (long)nb * 2 * C;     // [C]
+  float* c2 = c1 + C;
+  const double count = (double)B * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(C, 32), nb);
+#define S2S_BN_BWD(TT)                                                                                             \
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,     \
+                     ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                  \
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, nb, C, count, dgamma,      \
+                     dbeta, accumulate, c1, c2);                                                                   \
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,      \
+                     ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,       \
+                     dbias_conv ? part2 : nullptr, B, H, W, C);
+  if (dtype == S2S_BF16) { S2S_BN_BWD(bf16_t) }
+  else if (dtype == S2S_F32) { S2S_BN_BWD(float) }
+  else return S2S_ERR_DTYPE;
+#undef S2S_BN_BWD
+  if (dbias_conv)
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part2, nb, C, dbias_conv,
+                       accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

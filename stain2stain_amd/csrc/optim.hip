@@ -1,0 +1,168 @@
+// Optimiser step, weight packing and boundary layout conversion.
+//
+//   s2s_adam_step       torch.optim.Adam (coupled L2 weight decay, no amsgrad) over one flat fp32
+//                       parameter buffer -- the optimiser the reference builds in configure_optimizers
+//                       (src/models/conditional_flow_matching.py:112-131, configs/model/*.yaml:3-7).
+//   s2s_pack_conv3x3    OIHW fp32 master weights -> the two MFMA operand layouts of conv3x3_mfma.hip:
+//                       forward  Wf[tap][cin/32][cout][32]  and data-gradient
+//                       Wd[tap'][cout/32][cin][32] = W[co][ci][2-kh'][2-kw'] (flipped, transposed).
+//   s2s_nchw_to_nhwc / s2s_nhwc_to_nchw   fp32 NCHW <-> NHWC(T) at the module boundary (the reference's
+//                       boundary layout is NCHW contiguous fp32).
+#include "common.h"
+
+namespace {
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    float gi = g[i] * grad_scale;
+    if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout,
+                                    int Cin) {
+  const int nci = (Cin + 31) / 32, nco = (Cout + 31) / 32;
+  const long nf = 9L * nci * Cout * 32, nd = 9L * nco * Cin * 32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int k = (int)(i & 31);
+      long t = i >> 5;
+      const int co = (int)(t % Cout); t /= Cout;
+      const int c = (int)(t % nci);
+      const int tap = (int)(t / nci);
+      const int ci = c * 32 + k;
+      wf[i] = from_f32<T>(ci < Cin ? w[((long)co * Cin + ci) * 9 + tap] : 0.f);
+    } else if (wd) {
+      const long j = i - nf;
+      const int k = (int)(j & 31);
+      long t = j >> 5;
+      const int ci = (int)(t % Cin); t /= Cin;
+      const int c = (int)(t % nco);
+      const int tap = (int)(t / nco);
+      const int co = c * 32 + k;
+      wd[j] = from_f32<T>(co < Cout ? w[((long)co * Cin + ci) * 9 + (8 - tap)] : 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int ldy, int B, int C, int HW) {
+  const int cp = C >> 3;
+  const long total = (long)B * cp * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % HW);
+    long t = i / HW;
+    const int c8 = (int)(t % cp) * 8;
+    const int n = (int)(t / cp);
+    f32x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v.v[k] = x[((long)n * C + c8 + k) * HW + q];
+    store8(y + ((long)n * HW + q) * ldy + c8, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int B, int C, int HW,
+                                    int accumulate) {
+  const int cp = C >> 3;
+  const long total = (long)B * cp * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % HW);
+    long t = i / HW;
+    const int c8 = (int)(t % cp) * 8;
+    const int n = (int)(t / cp);
+    const f32x8 v = load8(x + ((long)n * HW + q) * ldx + c8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float* d = y + ((long)n * C + c8 + k) * HW + q;
+      *d = accumulate ? *d + v.v[k] : v.v[k];
+    }
+  }
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int s2s_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v) return S2S_ERR_NULL;
+  if (n <= 0 || step <= 0) return S2S_ERR_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// element counts of the two packed layouts (for the caller's allocation)
+extern "C" long s2s_pack_conv3x3_fwd_elems(int Cout, int Cin) { return 9L * ((Cin + 31) / 32) * Cout * 32; }
+extern "C" long s2s_pack_conv3x3_dgrad_elems(int Cout, int Cin) { return 9L * ((Cout + 31) / 32) * Cin * 32; }
+
+extern "C" int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
+                                void* stream) {
+  if (!w_oihw || !w_fwd) return S2S_ERR_NULL;
+  if (Cout <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
+  const long total = s2s_pack_conv3x3_fwd_elems(Cout, Cin) + (w_dgrad ? s2s_pack_conv3x3_dgrad_elems(Cout, Cin) : 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw, (bf16_t*)w_fwd,
+                       (bf16_t*)w_dgrad, Cout, Cin);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw, (float*)w_fwd,
+                       (float*)w_dgrad, Cout, Cin);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_nchw_to_nhwc(int dtype, const float* x_nchw, void* y, int ldy, int B, int C, int H, int W,
+                                void* stream) {
+  if (!x_nchw || !y) return S2S_ERR_NULL;
+  if (B <= 0 || C <= 0 || (C % 8) || (ldy % 8) || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  const long total = (long)B * (C / 8) * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, x_nchw, (bf16_t*)y, ldy, B, C,
+                       H * W);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, x_nchw, (float*)y, ldy, B, C,
+                       H * W);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accumulate, int B, int C, int H,
+                                int W, void* stream) {
+  if (!x || !y_nchw) return S2S_ERR_NULL;
+  if (B <= 0 || C <= 0 || (C % 8) || (ldx % 8) || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  const long total = (long)B * (C / 8) * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, ldx, y_nchw,
+                       B, C, H * W, accumulate);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, ldx, y_nchw, B,
+                       C, H * W, accumulate);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

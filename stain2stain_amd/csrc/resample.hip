@@ -1,0 +1,208 @@
+// Bilinear x2 up-sampling with align_corners=True (+ the zero pad to the skip's size), NHWC.
+//
+// Replaces nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) followed by F.pad in
+// the reference's Up block (src/models/components/task_decoders.py:34,42-47) and its backward.
+// The forward writes straight into a channel slice of the decoder's concat buffer (explicit pixel
+// stride), optionally adding the per-(sample, channel) time-conditioning bias to its input first
+// (FlowMatchingDecoder.forward: x = bottleneck + t[:, :, None, None], task_decoders.py:119-125).
+//
+// Index arithmetic follows ATen's upsample_bilinear2d: scale = (in-1)/(out-1) in fp32,
+// src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), w1 = src - i0, w0 = 1 - w1.
+#include "common.h"
+
+namespace {
+
+struct Axis {
+  int i0, i1;
+  float w0, w1;
+};
+
+__device__ __forceinline__ Axis ac_axis(int dst, int n_in, float scale) {
+  Axis a;
+  const float src = scale * (float)dst;
+  a.i0 = (int)src;
+  if (a.i0 > n_in - 1) a.i0 = n_in - 1;
+  a.i1 = a.i0 + (a.i0 < n_in - 1 ? 1 : 0);
+  a.w1 = src - (float)a.i0;
+  a.w0 = 1.f - a.w1;
+  return a;
+}
+
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ bias,
+                                      T* __restrict__ y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
+                                      int padT, int padL, int C) {
+  const int cp = C >> 3;
+  const int Hu = 2 * Hin, Wu = 2 * Win;
+  const float sh = Hu > 1 ? (float)(Hin - 1) / (float)(Hu - 1) : 0.f;
+  const float sw = Wu > 1 ? (float)(Win - 1) / (float)(Wu - 1) : 0.f;
+  const long total = (long)B * Hout * Wout * cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cp) * 8;
+    long t = i / cp;
+    const int ox = (int)(t % Wout); t /= Wout;
+    const int oy = (int)(t % Hout);
+    const int n = (int)(t / Hout);
+    const int uy = oy - padT, ux = ox - padL;
+    f32x8 o;
+    if (uy < 0 || uy >= Hu || ux < 0 || ux >= Wu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    } else {
+      const Axis ay = ac_axis(uy, Hin, sh), ax = ac_axis(ux, Win, sw);
+      const T* base = x + (long)n * Hin * Win * ldx + c8;
+      const f32x8 v00 = load8(base + ((long)ay.i0 * Win + ax.i0) * ldx);
+      const f32x8 v01 = load8(base + ((long)ay.i0 * Win + ax.i1) * ldx);
+      const f32x8 v10 = load8(base + ((long)ay.i1 * Win + ax.i0) * ldx);
+      const f32x8 v11 = load8(base + ((long)ay.i1 * Win + ax.i1) * ldx);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float b = bias ? bias[(long)n * C + c8 + k] : 0.f;
+        o.v[k] = ay.w0 * (ax.w0 * (v00.v[k] + b) + ax.w1 * (v01.v[k] + b)) +
+                 ay.w1 * (ax.w0 * (v10.v[k] + b) + ax.w1 * (v11.v[k] + b));
+      }
+    }
+    store8(y + (((long)n * Hout + oy) * Wout + ox) * ldy + c8, o);
+  }
+}
+
+// Gather form of the backward: input pixel (iy, ix) collects from every up-sampled pixel that read
+// it.  With scale < 1 at most 3 destination rows map their i0 or i1 onto one source row; the
+// candidates are bracketed from the inverse scale and tested exactly with the forward's own index
+// arithmetic, so forward and backward can never disagree.
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int B,
+                                      int Hin, int Win, int Hout, int Wout, int padT, int padL, int C) {
+  const int cp = C >> 3;
+  const int Hu = 2 * Hin, Wu = 2 * Win;
+  const float sh = Hu > 1 ? (float)(Hin - 1) / (float)(Hu - 1) : 0.f;
+  const float sw = Wu > 1 ? (float)(Win - 1) / (float)(Wu - 1) : 0.f;
+  const long total = (long)B * Hin * Win * cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cp) * 8;
+    long t = i / cp;
+    const int ix = (int)(t % Win); t /= Win;
+    const int iy = (int)(t % Hin);
+    const int n = (int)(t / Hin);
+    // candidate destination range: rows whose src coordinate lies in (iy-1, iy+1)
+    int y_lo, y_hi, x_lo, x_hi;
+    if (Hin == 1) { y_lo = 0; y_hi = Hu - 1; }
+    else {
+      y_lo = (int)floorf((float)(iy - 1) / sh) - 1; y_hi = (int)ceilf((float)(iy + 1) / sh) + 1;
+      if (y_lo < 0) y_lo = 0;
+      if (y_hi > Hu - 1) y_hi = Hu - 1;
+    }
+    if (Win == 1) { x_lo = 0; x_hi = Wu - 1; }
+    else {
+      x_lo = (int)floorf((float)(ix - 1) / sw) - 1; x_hi = (int)ceilf((float)(ix + 1) / sw) + 1;
+      if (x_lo < 0) x_lo = 0;
+      if (x_hi > Wu - 1) x_hi = Wu - 1;
+    }
+    f32x8 acc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+    for (int uy = y_lo; uy <= y_hi; ++uy) {
+      const Axis ay = ac_axis(uy, Hin, sh);
+      float wy = 0.f;
+      if (ay.i0 == iy) wy += ay.w0;
+      if (ay.i1 == iy) wy += ay.w1;
+      const int oy = uy + padT;
+      if (wy == 0.f || oy < 0 || oy >= Hout) continue;
+      for (int ux = x_lo; ux <= x_hi; ++ux) {
+        const Axis ax = ac_axis(ux, Win, sw);
+        float wx = 0.f;
+        if (ax.i0 == ix) wx += ax.w0;
+        if (ax.i1 == ix) wx += ax.w1;
+        const int ox = ux + padL;
+        if (wx == 0.f || ox < 0 || ox >= Wout) continue;
+        const f32x8 g = load8(dy + (((long)n * Hout + oy) * Wout + ox) * lddy + c8);
+        const float w = wy * wx;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.v[k] += w * g.v[k];
+      }
+    }
+    store8(dx + (((long)n * Hin + iy) * Win + ix) * lddx + c8, acc);
+  }
+}
+
+// out[n][c] (+)= sum over the H*W pixels of x[n][.][.][c]   (gradient of the broadcast time bias)
+template <typename T>
+__global__ void pixel_sum_kernel(const T* __restrict__ x, int ldx, float* __restrict__ out, int HW, int C,
+                                 int accumulate) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;  // 4 pixel groups
+  float s = 0.f;
+  if (c < C)
+    for (int p = rg; p < HW; p += 4) s += to_f32(x[((long)n * HW + p) * ldx + c]);
+  __shared__ float red[4][64];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    out[(long)n * C + c] = accumulate ? out[(long)n * C + c] + s : s;
+  }
+}
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int s2s_upsample2x_bilinear_ac_fwd(int dtype, const void* x, int ldx, const float* bias_nc, void* y,
+                                              int ldy, int B, int Hin, int Win, int Hout, int Wout, int C,
+                                              void* stream) {
+  if (!x || !y) return S2S_ERR_NULL;
+  if (B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8)) return S2S_ERR_SHAPE;
+  if (Hout < 2 * Hin || Wout < 2 * Win) return S2S_ERR_SHAPE;  // F.pad with a negative size (crop) is not supported
+  const int padT = (Hout - 2 * Hin) / 2, padL = (Wout - 2 * Win) / 2;
+  const long total = (long)B * Hout * Wout * (C / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       bias_nc, (bf16_t*)y, ldy, B, Hin, Win, Hout, Wout, padT, padL, C);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, ldx,
+                       bias_nc, (float*)y, ldy, B, Hin, Win, Hout, Wout, padT, padL, C);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_upsample2x_bilinear_ac_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int B, int Hin,
+                                              int Win, int Hout, int Wout, int C, void* stream) {
+  if (!dy || !dx) return S2S_ERR_NULL;
+  if (B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || (C % 8) || (lddy % 8) || (lddx % 8)) return S2S_ERR_SHAPE;
+  if (Hout < 2 * Hin || Wout < 2 * Win) return S2S_ERR_SHAPE;
+  const int padT = (Hout - 2 * Hin) / 2, padL = (Wout - 2 * Win) / 2;
+  const long total = (long)B * Hin * Win * (C / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)dy, lddy,
+                       (bf16_t*)dx, lddx, B, Hin, Win, Hout, Wout, padT, padL, C);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)dy, lddy,
+                       (float*)dx, lddx, B, Hin, Win, Hout, Wout, padT, padL, C);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_pixel_sum(int dtype, const void* x, int ldx, float* out_nc, int B, int HW, int C, int accumulate,
+                             void* stream) {
+  if (!x || !out_nc) return S2S_ERR_NULL;
+  if (B <= 0 || HW <= 0 || C <= 0) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(C, 64), B);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(pixel_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out_nc, HW, C, accumulate);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pixel_sum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out_nc, HW, C, accumulate);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

@@ -1,0 +1,238 @@
+"""Forward / backward schedules of the U-Net over the HIP ops (no autograd, no torch math).
+
+The functions here walk the parameter containers defined in ``components.py`` and issue the kernel
+sequence for
+
+  * ``encoder_forward`` / ``encoder_backward``   SharedEncoder.forward (reference
+    src/models/components/shared_encoder.py:75-104) and its autograd backward
+  * ``decoder_forward`` / ``decoder_backward``   FlowMatchingDecoder.forward (task_decoders.py:102-134)
+
+Every intermediate is an NHWC tensor in the compute dtype (bf16, or fp32 for the split-MFMA parity
+mode) allocated from torch's caching allocator; a forward returns a context object that owns what
+its backward needs, so two forwards may be alive at once (the multitask module runs the encoder
+twice per step, conditional_flow_matching_multitask.py:228,236).
+
+Gradients are written into ``grads[name]`` (fp32, parameter-shaped, e.g. views of one flat bucket
+buffer); with ``accumulate=True`` they are added to what is there.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter bundles
+# ------------------------------------------------------------------------------------------------
+class ConvBN:
+    """One Conv3x3 + BatchNorm2d pair of a DoubleConv, with its packed MFMA weight cache."""
+
+    def __init__(self, prefix: str, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d):
+        self.prefix = prefix            # e.g. "inc.double_conv"
+        self.conv, self.bn = conv, bn
+        idx = {"0": ("0", "1"), "3": ("3", "4")}
+        self._pack: Dict[torch.dtype, Tuple] = {}
+        self._pack_key: Dict[torch.dtype, Tuple] = {}
+
+    @property
+    def cout(self) -> int:
+        return self.conv.weight.shape[0]
+
+    @property
+    def cin(self) -> int:
+        return self.conv.weight.shape[1]
+
+    def packed(self, dtype: torch.dtype):
+        """(forward, dgrad) MFMA layouts of the fp32 OIHW master weight; repacked when it changes."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._pack_key.get(dtype) != key:
+            old = self._pack.get(dtype)
+            reuse = old if (old is not None and old[0].device == w.device) else None
+            self._pack[dtype] = ops.pack_conv3x3(w.detach(), dtype, want_dgrad=True, out=reuse)
+            self._pack_key[dtype] = key
+        return self._pack[dtype]
+
+    def invalidate(self) -> None:
+        self._pack_key.clear()
+
+
+@dataclass
+class LayerCtx:
+    """What one conv+BN+ReLU layer keeps for its backward."""
+    x0: Optional[torch.Tensor]          # conv input (NHWC), or the NCHW image for the stem
+    x1: Optional[torch.Tensor]
+    raw: torch.Tensor                   # conv output
+    act: torch.Tensor                   # ReLU output
+    stats: torch.Tensor                 # [4, C]: mean, invstd, scale, shift
+
+
+@dataclass
+class EncCtx:
+    dtype: torch.dtype
+    x_nchw: torch.Tensor
+    layers: List[Tuple[LayerCtx, LayerCtx]] = field(default_factory=list)   # per level: (conv1, conv2)
+    feats: List[torch.Tensor] = field(default_factory=list)                 # act of conv2 per level
+
+
+@dataclass
+class DecCtx:
+    dtype: torch.dtype
+    t_emb: torch.Tensor
+    h1: torch.Tensor = None             # time_mlp.0 pre-activation
+    a1: torch.Tensor = None             # SiLU output
+    h2: torch.Tensor = None             # time_mlp.2 output
+    lows: List[torch.Tensor] = field(default_factory=list)    # input of each up-sampling
+    ups: List[torch.Tensor] = field(default_factory=list)
+    skips: List[torch.Tensor] = field(default_factory=list)
+    layers: List[Tuple[LayerCtx, LayerCtx]] = field(default_factory=list)
+    v: torch.Tensor = None
+
+
+def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = False, stem: bool = False):
+    """Returns (LayerCtx or None, act, pooled)."""
+    bn = cb.bn
+    bias = cb.conv.bias.detach() if cb.conv.bias is not None else None
+    if training:
+        if stem:
+            raw, stat = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=True)
+        else:
+            raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
+        count = raw.shape[0] * raw.shape[1] * raw.shape[2]
+        track = bn.track_running_stats and bn.running_mean is not None
+        st = ops.bn_finalize(stat, count, bn.weight.detach(), bn.bias.detach(),
+                             bn.running_mean if track else None, bn.running_var if track else None,
+                             bn.num_batches_tracked if track else None,
+                             BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps)
+        act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
+        return LayerCtx(x0, x1, raw, act, st), act, pooled
+    ss = ops.bn_eval_prepare(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+    if stem:
+        raw, _ = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=False)
+        act, pooled = ops.bn_relu_apply(raw, ss[0], ss[1], want_pool=want_pool)
+    else:
+        # eval-mode BatchNorm + ReLU folded into the MFMA epilogue: the conv writes the activation directly
+        act, _ = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, scale=ss[0], shift=ss[1], relu=True)
+        pooled = ops.maxpool2(act) if want_pool else None
+    return None, act, pooled
+
+
+def _g(grads: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+    try:
+        return grads[name]
+    except KeyError as e:
+        raise RuntimeError(f"stain2stain_amd: no gradient buffer for parameter {name!r}") from e
+
+
+def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool, need_dx: bool, stem: bool = False):
+    """Backward of conv -> BN -> ReLU.  g1/gp: gradient wrt the activation / wrt its 2x2 max-pool."""
+    p = cb.prefix
+    i_conv, i_bn = cb.idx
+    dgamma = _g(grads, f"{p}.{i_bn}.weight")
+    dbeta = _g(grads, f"{p}.{i_bn}.bias")
+    dbias = _g(grads, f"{p}.{i_conv}.bias") if cb.conv.bias is not None else None
+    draw = ops.bn_relu_bwd(g1, gp, lc.act, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
+    dw = _g(grads, f"{p}.{i_conv}.weight")
+    if stem:
+        ops.stem_wgrad(draw, lc.x0, dw, None, accumulate)
+        return None
+    ops.conv3x3_wgrad(draw, lc.x0, lc.x1, dw, accumulate)
+    if not need_dx:
+        return None
+    dx, _ = ops.conv3x3(draw, None, cb.packed(draw.dtype)[1], None, cb.cin)
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder
+# ------------------------------------------------------------------------------------------------
+def encoder_forward(blocks: Sequence[Tuple[ConvBN, ConvBN]], x_nchw: torch.Tensor, dtype: torch.dtype,
+                    training: bool) -> EncCtx:
+    """blocks[l] = (conv1, conv2) of level l (l = 0 is ``inc``).  Keeps every level's activation."""
+    ctx = EncCtx(dtype, x_nchw)
+    nlev = len(blocks)
+    inp = x_nchw
+    for l, (c1, c2) in enumerate(blocks):
+        lc1, a1, _ = _conv_bn_relu(c1, inp, None, dtype, training, stem=(l == 0))
+        lc2, a2, pooled = _conv_bn_relu(c2, a1, None, dtype, training, want_pool=(l + 1 < nlev))
+        ctx.layers.append((lc1, lc2))
+        ctx.feats.append(a2)
+        inp = pooled
+    return ctx
+
+
+def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeats: Sequence[Optional[torch.Tensor]],
+                     grads: Dict[str, torch.Tensor], accumulate: bool = False) -> None:
+    """dfeats[l]: gradient wrt level l's output activation (NHWC, or None); the max-pool path between the
+    levels is handled here."""
+    gpool = None
+    for l in range(len(blocks) - 1, -1, -1):
+        c1, c2 = blocks[l]
+        lc1, lc2 = ctx.layers[l]
+        g1 = dfeats[l]
+        if g1 is None and gpool is None:
+            raise RuntimeError("stain2stain_amd: encoder level without any incoming gradient")
+        ga1 = _conv_bn_relu_bwd(c2, lc2, g1, gpool, grads, accumulate, need_dx=True)
+        gpool = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=(l > 0), stem=(l == 0))
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder
+# ------------------------------------------------------------------------------------------------
+def decoder_forward(dec, bottleneck: torch.Tensor, skips: Sequence[torch.Tensor], t_emb: torch.Tensor,
+                    dtype: torch.dtype, training: bool) -> DecCtx:
+    """dec: FlowMatchingDecoder container (time_mlp, time_proj, up_blocks, outc)."""
+    ctx = DecCtx(dtype, t_emb)
+    l0, l2 = dec.time_mlp[0], dec.time_mlp[2]
+    ctx.h1 = ops.linear_fwd(t_emb, l0.weight.detach(), l0.bias.detach())
+    ctx.a1 = ops.silu_fwd(ctx.h1)
+    ctx.h2 = ops.linear_fwd(ctx.a1, l2.weight.detach(), l2.bias.detach())
+    tbias = ops.linear_fwd(ctx.h2, dec.time_proj.weight.detach(), dec.time_proj.bias.detach())  # [B, Cb]
+    x = bottleneck
+    for i, ((c1, c2), skip) in enumerate(zip(dec.up_blocks, skips)):
+        B, Hs, Ws, _ = skip.shape
+        up = torch.empty((B, Hs, Ws, x.shape[3]), dtype=dtype, device=x.device)
+        ops.upsample2x_fwd(x, up, tbias if i == 0 else None)
+        lc1, a1, _ = _conv_bn_relu(c1, skip, up, dtype, training)
+        lc2, a2, _ = _conv_bn_relu(c2, a1, None, dtype, training)
+        ctx.lows.append(x); ctx.ups.append(up); ctx.skips.append(skip); ctx.layers.append((lc1, lc2))
+        x = a2
+    ctx.lows.append(x)  # head input
+    ctx.v = ops.head_fwd(x, dec.outc.weight.detach(), dec.outc.bias.detach() if dec.outc.bias is not None else None)
+    return ctx
+
+
+def decoder_backward(dec, ctx: DecCtx, dv: torch.Tensor, grads: Dict[str, torch.Tensor], accumulate: bool = False,
+                     need_dt_emb: bool = False):
+    """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype."""
+    g = ops.head_bwd(dv, ctx.lows[-1], dec.outc.weight.detach(), _g(grads, "outc.weight"),
+                     _g(grads, "outc.bias") if dec.outc.bias is not None else None, accumulate)
+    dskips: List[torch.Tensor] = [None] * len(ctx.layers)
+    for i in range(len(ctx.layers) - 1, -1, -1):
+        c1, c2 = dec.up_blocks[i]
+        lc1, lc2 = ctx.layers[i]
+        ga1 = _conv_bn_relu_bwd(c2, lc2, g, None, grads, accumulate, need_dx=True)
+        dcat = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=True)
+        cs = ctx.skips[i].shape[3]
+        dskips[i] = dcat[..., :cs]
+        low = ctx.lows[i]
+        g = ops.upsample2x_bwd(dcat[..., cs:], low.shape[1], low.shape[2])
+    dbott = g
+    # time path: tbias was broadcast-added to the bottleneck before the first up-sampling
+    dtb = ops.pixel_sum(g)
+    l0, l2 = dec.time_mlp[0], dec.time_mlp[2]
+    dh2 = ops.linear_bwd(dtb, ctx.h2, dec.time_proj.weight.detach(), _g(grads, "time_proj.weight"),
+                         _g(grads, "time_proj.bias"), True, accumulate)
+    da1 = ops.linear_bwd(dh2, ctx.a1, l2.weight.detach(), _g(grads, "time_mlp.2.weight"),
+                         _g(grads, "time_mlp.2.bias"), True, accumulate)
+    dh1 = ops.silu_bwd(ctx.h1, da1)
+    dt_emb = ops.linear_bwd(dh1, ctx.t_emb, l0.weight.detach(), _g(grads, "time_mlp.0.weight"),
+                            _g(grads, "time_mlp.0.bias"), need_dt_emb, accumulate)
+    return dbott, dskips, dt_emb

@@ -1,0 +1,386 @@
+"""Tensor-level wrappers over the C ABI (include/stain2stain_hip.h).
+
+Activations are torch tensors of logical shape [B, H, W, C] (NHWC) whose last dim is contiguous; a
+channel slice of a wider NHWC buffer is a valid operand (its pixel stride is passed as ``ld``).
+dtype bf16 -> throughput mode, float32 -> split-bf16 parity mode.  Every wrapper validates on the
+host what the kernel assumes, launches on torch's current stream, and turns a non-zero status into
+RuntimeError (the reference's only error convention is Python exceptions, src/utils/utils.py:65-80).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native
+
+BF16, F32 = 0, 1
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise RuntimeError(f"stain2stain_amd: unsupported activation dtype {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _nhwc(t: torch.Tensor) -> Tuple[int, int]:
+    """(data_ptr, pixel stride) of an NHWC view; raises if the view is not expressible as base+ld."""
+    if not t.is_cuda:
+        raise RuntimeError("stain2stain_amd: tensor is not on the GPU (there is no CPU path)")
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise RuntimeError("stain2stain_amd: expected an NHWC view with contiguous channels")
+    b, h, w, _ = t.shape
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else t.shape[3])
+    if w > 1 and h > 1 and t.stride(1) != w * ld:
+        raise RuntimeError("stain2stain_amd: NHWC view has a row pitch")
+    if b > 1 and t.stride(0) != h * w * ld:
+        raise RuntimeError("stain2stain_amd: NHWC view has an image pitch")
+    return t.data_ptr(), ld
+
+
+def _f32(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError("stain2stain_amd: expected a contiguous fp32 GPU tensor")
+    return t.data_ptr()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError("stain2stain_amd: expected a contiguous GPU tensor")
+    return t.data_ptr()
+
+
+def _L():
+    return _native.lib()
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions
+# ------------------------------------------------------------------------------------------------
+def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+            cout: int, *, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
+            shift: Optional[torch.Tensor] = None, relu: bool = False, out: Optional[torch.Tensor] = None):
+    """y[B,H,W,cout] = conv3x3(cat([x0, x1], C)); returns (y, stat_part or None)."""
+    B, H, W, c0 = x0.shape
+    dt = _dt(x0)
+    p0, ld0 = _nhwc(x0)
+    p1, ld1, c1 = 0, 8, 0
+    if x1 is not None:
+        if x1.shape[:3] != x0.shape[:3] or x1.dtype != x0.dtype:
+            raise RuntimeError("stain2stain_amd: conv3x3 sources disagree in shape/dtype")
+        p1, ld1 = _nhwc(x1)
+        c1 = x1.shape[3]
+    if w_packed.dtype != x0.dtype or w_packed.numel() != _L().s2s_pack_conv3x3_fwd_elems(cout, c0 + c1):
+        raise RuntimeError("stain2stain_amd: packed weight does not match (cout, cin, dtype)")
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=x0.dtype, device=x0.device)
+    elif out.shape != (B, H, W, cout) or out.dtype != x0.dtype:
+        raise RuntimeError("stain2stain_amd: conv3x3 output buffer mismatch")
+    py, ldy = _nhwc(out)
+    stat = None
+    if want_stats:
+        nb = _L().s2s_conv3x3_stat_blocks(B, H, W, cout)
+        stat = torch.empty((nb, 2, cout), dtype=torch.float32, device=x0.device)
+    rc = _L().s2s_conv3x3_nhwc(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
+                               _f32(scale), _f32(shift), int(relu), B, H, W, cout, _stream())
+    _native.check(rc, "conv3x3")
+    return out, stat
+
+
+def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], grad_oihw: torch.Tensor,
+                  accumulate: bool = False) -> None:
+    B, H, W, cout = dy.shape
+    c0 = x0.shape[3]
+    dt = _dt(dy)
+    if x0.dtype != dy.dtype or x0.shape[:3] != dy.shape[:3]:
+        raise RuntimeError("stain2stain_amd: conv3x3_wgrad operand mismatch")
+    pdy, lddy = _nhwc(dy)
+    p0, ld0 = _nhwc(x0)
+    p1, ld1, c1 = 0, 8, 0
+    if x1 is not None:
+        p1, ld1 = _nhwc(x1)
+        c1 = x1.shape[3]
+    if tuple(grad_oihw.shape) != (cout, c0 + c1, 3, 3):
+        raise RuntimeError("stain2stain_amd: conv3x3_wgrad gradient buffer has the wrong shape")
+    s = _L().s2s_conv3x3_wgrad_splits(B, H, W, c0 + c1, cout)
+    part = torch.empty((s, 9, cout, c0 + c1), dtype=torch.float32, device=dy.device)
+    rc = _L().s2s_conv3x3_wgrad_nhwc(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
+                                     int(accumulate), B, H, W, _stream())
+    _native.check(rc, "conv3x3_wgrad")
+
+
+def stem_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
+             want_stats: bool = True):
+    B, cin, H, W = x_nchw.shape
+    cout = w.shape[0]
+    if tuple(w.shape) != (cout, cin, 3, 3):
+        raise RuntimeError("stain2stain_amd: stem weight shape")
+    y = torch.empty((B, H, W, cout), dtype=dtype, device=x_nchw.device)
+    stat = None
+    if want_stats:
+        stat = torch.empty((_L().s2s_stem_stat_blocks(B, H, W), 2, cout), dtype=torch.float32, device=y.device)
+    rc = _L().s2s_stem_conv3x3_fwd(_dt(y), _f32(x_nchw), _f32(w), _f32(bias), y.data_ptr(), cout, _f32(stat), B, H, W,
+                                   cin, cout, _stream())
+    _native.check(rc, "stem_conv3x3_fwd")
+    return y, stat
+
+
+def stem_wgrad(dy: torch.Tensor, x_nchw: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor],
+               accumulate: bool = False) -> None:
+    B, H, W, cout = dy.shape
+    cin = x_nchw.shape[1]
+    pdy, lddy = _nhwc(dy)
+    nb = _L().s2s_stem_wgrad_blocks(B, H, W)
+    part = torch.empty((nb, cout, cin * 9 + 1), dtype=torch.float32, device=dy.device)
+    rc = _L().s2s_stem_conv3x3_wgrad(_dt(dy), pdy, lddy, _f32(x_nchw), _f32(part), _f32(dw), _f32(dbias),
+                                     int(accumulate), B, H, W, cin, cout, _stream())
+    _native.check(rc, "stem_conv3x3_wgrad")
+
+
+def head_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    B, H, W, C = x.shape
+    cout = w.shape[0]
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_head_conv1x1_fwd(_dt(x), px, ldx, _f32(w.reshape(cout, C)), _f32(bias), _f32(y), B, H, W, C, cout,
+                                   _stream())
+    _native.check(rc, "head_conv1x1_fwd")
+    return y
+
+
+def head_bwd(dy_nchw: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor],
+             accumulate: bool = False) -> torch.Tensor:
+    B, H, W, C = x.shape
+    cout = w.shape[0]
+    px, ldx = _nhwc(x)
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    nb = _L().s2s_head_wgrad_blocks(B, H, W)
+    part = torch.empty((nb, cout, C + 1), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_head_conv1x1_bwd(_dt(x), _f32(dy_nchw), px, ldx, _f32(w.reshape(cout, C)), dx.data_ptr(), C,
+                                   _f32(part), _f32(dw.reshape(cout, C)), _f32(dbias), int(accumulate), B, H, W, C,
+                                   cout, _stream())
+    _native.check(rc, "head_conv1x1_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm + ReLU (+ pool)
+# ------------------------------------------------------------------------------------------------
+def bn_finalize(stat: torch.Tensor, count: int, gamma, beta, running_mean, running_var, num_batches,
+                momentum: float = 0.1, eps: float = 1e-5):
+    nblk, _, C = stat.shape
+    dev = stat.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+    rc = _L().s2s_bn_finalize(_f32(stat), nblk, C, count, _f32(gamma), _f32(beta), _f32(running_mean),
+                              _f32(running_var), 0 if num_batches is None else num_batches.data_ptr(), momentum, eps,
+                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    _native.check(rc, "bn_finalize")
+    return out
+
+
+def bn_eval_prepare(gamma, beta, rmean, rvar, eps: float = 1e-5):
+    C = gamma.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    rc = _L().s2s_bn_eval_prepare(C, _f32(gamma), _f32(beta), _f32(rmean), _f32(rvar), eps, out[0].data_ptr(),
+                                  out[1].data_ptr(), _stream())
+    _native.check(rc, "bn_eval_prepare")
+    return out
+
+
+def bn_relu_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out: Optional[torch.Tensor] = None,
+                  pool: Optional[torch.Tensor] = None, want_pool: bool = False):
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    py, ldy = _nhwc(out)
+    pp, ldp = 0, 8
+    if want_pool and pool is None:
+        pool = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    if pool is not None:
+        pp, ldp = _nhwc(pool)
+    rc = _L().s2s_bn_relu_apply(_dt(x), px, ldx, _f32(scale), _f32(shift), py, ldy, pp, ldp, B, H, W, C, _stream())
+    _native.check(rc, "bn_relu_apply")
+    return out, pool
+
+
+def maxpool2(x: torch.Tensor) -> torch.Tensor:
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    pool = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    rc = _L().s2s_maxpool2(_dt(x), px, ldx, pool.data_ptr(), C, B, H, W, C, _stream())
+    _native.check(rc, "maxpool2")
+    return pool
+
+
+def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], y: torch.Tensor, x: torch.Tensor,
+                stats: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                dbias_conv: Optional[torch.Tensor], accumulate: bool = False) -> torch.Tensor:
+    """Returns dx (gradient wrt the conv output).  stats = bn_finalize() output (rows mean, invstd, ...)."""
+    B, H, W, C = y.shape
+    py, ldy = _nhwc(y)
+    px, ldx = _nhwc(x)
+    p1, ld1 = (0, 8) if g1 is None else _nhwc(g1)
+    p2, ld2 = (0, 8) if gp is None else _nhwc(gp)
+    dx = torch.empty((B, H, W, C), dtype=y.dtype, device=y.device)
+    nb = _L().s2s_bn_bwd_blocks(B, H, W, C)
+    work = torch.empty((4 * nb * C + 2 * C,), dtype=torch.float32, device=y.device)
+    rc = _L().s2s_bn_relu_bwd(_dt(y), p1, ld1, p2, ld2, py, ldy, px, ldx, stats[0].data_ptr(), stats[1].data_ptr(),
+                              _f32(gamma), _f32(dgamma), _f32(dbeta), _f32(dbias_conv), int(accumulate),
+                              dx.data_ptr(), C, _f32(work), B, H, W, C, _stream())
+    _native.check(rc, "bn_relu_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# resampling
+# ------------------------------------------------------------------------------------------------
+def upsample2x_fwd(x: torch.Tensor, out: torch.Tensor, bias_nc: Optional[torch.Tensor] = None) -> None:
+    B, Hin, Win, C = x.shape
+    _, Hout, Wout, Co = out.shape
+    if Co != C or out.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: upsample output slice mismatch")
+    px, ldx = _nhwc(x)
+    py, ldy = _nhwc(out)
+    rc = _L().s2s_upsample2x_bilinear_ac_fwd(_dt(x), px, ldx, _f32(bias_nc), py, ldy, B, Hin, Win, Hout, Wout, C,
+                                             _stream())
+    _native.check(rc, "upsample2x_fwd")
+
+
+def upsample2x_bwd(dy: torch.Tensor, hin: int, win: int) -> torch.Tensor:
+    B, Hout, Wout, C = dy.shape
+    pdy, lddy = _nhwc(dy)
+    dx = torch.empty((B, hin, win, C), dtype=dy.dtype, device=dy.device)
+    rc = _L().s2s_upsample2x_bilinear_ac_bwd(_dt(dy), pdy, lddy, dx.data_ptr(), C, B, hin, win, Hout, Wout, C,
+                                             _stream())
+    _native.check(rc, "upsample2x_bwd")
+    return dx
+
+
+def pixel_sum(x: torch.Tensor) -> torch.Tensor:
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_pixel_sum(_dt(x), px, ldx, _f32(out), B, H * W, C, 0, _stream())
+    _native.check(rc, "pixel_sum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# flow-matching glue
+# ------------------------------------------------------------------------------------------------
+def time_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    t = t.reshape(-1).to(torch.float32).contiguous()
+    out = torch.empty((t.numel(), dim), dtype=torch.float32, device=t.device)
+    _native.check(_L().s2s_time_embedding(_f32(t), _f32(out), t.numel(), dim, _stream()), "time_embedding")
+    return out
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _native.check(_L().s2s_linear_fwd(_f32(x), _f32(w), _f32(b), _f32(y), B, K, N, _stream()), "linear_fwd")
+    return y
+
+
+def linear_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor],
+               need_dx: bool = True, accumulate: bool = False) -> Optional[torch.Tensor]:
+    B, K = x.shape
+    N = w.shape[0]
+    dx = torch.empty((B, K), dtype=torch.float32, device=x.device) if need_dx else None
+    _native.check(_L().s2s_linear_bwd(_f32(dy), _f32(x), _f32(w), _f32(dx), _f32(dw), _f32(db), int(accumulate), B, K,
+                                      N, _stream()), "linear_bwd")
+    return dx
+
+
+def silu_fwd(h: torch.Tensor) -> torch.Tensor:
+    a = torch.empty_like(h)
+    _native.check(_L().s2s_silu_fwd(_f32(h), _f32(a), h.numel(), _stream()), "silu_fwd")
+    return a
+
+
+def silu_bwd(h: torch.Tensor, da: torch.Tensor) -> torch.Tensor:
+    dh = torch.empty_like(h)
+    _native.check(_L().s2s_silu_bwd(_f32(h), _f32(da), _f32(dh), h.numel(), _stream()), "silu_bwd")
+    return dh
+
+
+def cfm_sample(x0: torch.Tensor, x1: torch.Tensor, t: torch.Tensor, sigma: float = 0.0,
+               eps: Optional[torch.Tensor] = None):
+    xt = torch.empty_like(x0)
+    ut = torch.empty_like(x0)
+    B = x0.shape[0]
+    _native.check(_L().s2s_cfm_sample(_f32(x0), _f32(x1), _f32(t), _f32(eps), float(sigma), _f32(xt), _f32(ut), B,
+                                      x0.numel() // B, _stream()), "cfm_sample")
+    return xt, ut
+
+
+def mse_loss(v: torch.Tensor, u: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
+    loss = torch.empty((), dtype=torch.float32, device=v.device)
+    dv = torch.empty_like(v) if want_grad else None
+    work = torch.empty((1024,), dtype=torch.float64, device=v.device)
+    _native.check(_L().s2s_mse_loss(_f32(v), _f32(u), _f32(dv), float(grad_scale), loss.data_ptr(), work.data_ptr(),
+                                    v.numel(), _stream()), "mse_loss")
+    return loss, dv
+
+
+def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:
+    _native.check(_L().s2s_axpy(_f32(x), _f32(y), float(a), x.numel(), _stream()), "axpy")
+
+
+def fill_(x: torch.Tensor, v: float) -> None:
+    _native.check(_L().s2s_fill_f32(_f32(x), float(v), x.numel(), _stream()), "fill")
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / packing / layout
+# ------------------------------------------------------------------------------------------------
+def adam_step_(p, g, m, v, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+               weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:
+    _native.check(_L().s2s_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), int(step), float(lr), float(beta1),
+                                     float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream()),
+                  "adam_step")
+
+
+def pack_conv3x3(w_oihw: torch.Tensor, dtype: torch.dtype, want_dgrad: bool = True, out=None):
+    cout, cin = w_oihw.shape[:2]
+    dev = w_oihw.device
+    if out is None:
+        wf = torch.empty((_L().s2s_pack_conv3x3_fwd_elems(cout, cin),), dtype=dtype, device=dev)
+        wd = torch.empty((_L().s2s_pack_conv3x3_dgrad_elems(cout, cin),), dtype=dtype, device=dev) if want_dgrad else None
+    else:
+        wf, wd = out
+    rc = _L().s2s_pack_conv3x3(_dt(wf), _f32(w_oihw), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), cout, cin,
+                               _stream())
+    _native.check(rc, "pack_conv3x3")
+    return wf, wd
+
+
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=dtype, device=x.device)
+    py, ldy = _nhwc(out)
+    _native.check(_L().s2s_nchw_to_nhwc(_dt(out), _f32(x), py, ldy, B, C, H, W, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _native.check(_L().s2s_nhwc_to_nchw(_dt(x), px, ldx, _f32(out), int(accumulate), B, C, H, W, _stream()),
+                  "nhwc_to_nchw")
+    return out

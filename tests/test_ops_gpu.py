@@ -1,0 +1,290 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point against the fp32 CPU oracle ops.
+
+Tolerances (max-norm relative, stated per test):
+  * fp32 "split" mode (hi/lo bf16 MFMA, fp32 accumulate) vs the fp32 oracle: 1e-4 (well inside the 1e-3
+    north-star bound; expected ~1e-5).
+  * bf16 mode vs the oracle evaluated on bf16-rounded operands: 4e-3 for bf16-stored outputs (one bf16
+    rounding of the result is 2^-9 = 2e-3), 1e-4 for fp32 outputs (statistics, weight gradients).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dtype):
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+
+
+def tol_act(dtype):
+    return 4e-3 if dtype == torch.bfloat16 else 1e-4
+
+
+CONV_CASES = [
+    # B, H, W, c0, c1, cout
+    (2, 20, 37, 16, 0, 24),     # odd sizes, N tail (cout < 64 config)
+    (1, 16, 16, 64, 0, 128),    # narrow-image config
+    (2, 32, 64, 32, 48, 160),   # two sources (concat), cout tail in the 128 config
+    (1, 9, 70, 8, 8, 72),       # chunk straddles the two sources, W tail
+    (3, 12, 10, 40, 0, 200),    # narrow + everything ragged
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_forward_and_stats(case, dtype):
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(B, c0 + c1, H, W, generator=g) * 2 - 1
+    w = (torch.rand(cout, c0 + c1, 3, 3, generator=g) * 2 - 1) * 0.1
+    b = torch.rand(cout, generator=g) - 0.5
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    xs = nhwc(x, dtype)
+    # sources as channel slices of one wider buffer (exercises the pixel stride)
+    x0 = xs[..., :c0]
+    x1 = xs[..., c0:] if c1 else None
+    wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
+    y, stat = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, want_stats=True)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), ref) < tol_act(dtype)
+    s = stat.sum(0).cpu()
+    assert relerr(s[0], ref.sum((0, 2, 3))) < 2e-4 + (1e-3 if dtype == torch.bfloat16 else 0)
+    assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 2e-4 + (1e-3 if dtype == torch.bfloat16 else 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_epilogue_affine_relu(dtype):
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 32, 18, 33, generator=g) * 2 - 1
+    w = (torch.rand(64, 32, 3, 3, generator=g) * 2 - 1) * 0.1
+    b = torch.rand(64, generator=g) - 0.5
+    sc = torch.rand(64, generator=g) + 0.5
+    sh = torch.rand(64, generator=g) - 0.5
+    ref = (F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1) * sc[None, :, None, None]
+           + sh[None, :, None, None]).clamp_min(0)
+    wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
+    y, _ = ops.conv3x3(nhwc(x, dtype), None, wf, b.to(DEV), 64, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    assert relerr(nchw(y), ref) < tol_act(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_dgrad(case, dtype):
+    """Data gradient = the same kernel on the flipped/transposed packing."""
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout = case
+    cin = c0 + c1
+    g = torch.Generator().manual_seed(9)
+    w = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) * 0.1
+    dy = torch.rand(B, cout, H, W, generator=g) * 2 - 1
+    x = torch.zeros(B, cin, H, W, requires_grad=True)
+    (F.conv2d(x, rnd(w, dtype), None, padding=1) * rnd(dy, dtype)).sum().backward()
+    _, wd = ops.pack_conv3x3(w.to(DEV), dtype)
+    dx, _ = ops.conv3x3(nhwc(dy, dtype), None, wd, None, cin)
+    assert relerr(nchw(dx), x.grad) < tol_act(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_wgrad(case, dtype):
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout = case
+    cin = c0 + c1
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(B, cin, H, W, generator=g) * 2 - 1
+    dy = torch.rand(B, cout, H, W, generator=g) * 2 - 1
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    (F.conv2d(rnd(x, dtype), w, None, padding=1) * rnd(dy, dtype)).sum().backward()
+    xs = nhwc(x, dtype)
+    grad = torch.full((cout, cin, 3, 3), 7.0, device=DEV)
+    ops.conv3x3_wgrad(nhwc(dy, dtype), xs[..., :c0], xs[..., c0:] if c1 else None, grad, accumulate=False)
+    assert relerr(grad.cpu(), w.grad) < 1e-4
+    ops.conv3x3_wgrad(nhwc(dy, dtype), xs[..., :c0], xs[..., c0:] if c1 else None, grad, accumulate=True)
+    assert relerr(grad.cpu(), 2 * w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_and_head(dtype):
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 21, 30, generator=g) * 2 - 1
+    w = (torch.rand(16, 3, 3, 3, generator=g) * 2 - 1) * 0.3
+    b = torch.rand(16, generator=g) - 0.5
+    ref = F.conv2d(x, w, b, padding=1)
+    y, stat = ops.stem_fwd(x.to(DEV), w.to(DEV), b.to(DEV), dtype)
+    assert relerr(nchw(y), ref) < tol_act(dtype)
+    s = stat.sum(0).cpu()
+    assert relerr(s[0], ref.sum((0, 2, 3))) < 1e-4
+    assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-4
+    # stem weight/bias gradient
+    dy = torch.rand(2, 16, 21, 30, generator=g) * 2 - 1
+    wv = w.clone().requires_grad_(True)
+    bv = b.clone().requires_grad_(True)
+    (F.conv2d(x, wv, bv, padding=1) * rnd(dy, dtype)).sum().backward()
+    dw = torch.empty(16, 3, 3, 3, device=DEV)
+    db = torch.empty(16, device=DEV)
+    ops.stem_wgrad(nhwc(dy, dtype), x.to(DEV), dw, db)
+    assert relerr(dw.cpu(), wv.grad) < 1e-4
+    assert relerr(db.cpu(), bv.grad) < 1e-4
+    # head 1x1
+    a = torch.rand(2, 16, 21, 30, generator=g) * 2 - 1
+    hw = ((torch.rand(3, 16, 1, 1, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    hb = (torch.rand(3, generator=g) - 0.5).requires_grad_(True)
+    av = rnd(a, dtype).requires_grad_(True)
+    out = F.conv2d(av, hw, hb)
+    v = ops.head_fwd(nhwc(a, dtype), hw.detach().to(DEV), hb.detach().to(DEV))
+    assert relerr(v.cpu(), out) < 1e-5
+    dv = torch.rand(out.shape, generator=g) - 0.5
+    (out * dv).sum().backward()
+    dw = torch.empty(3, 16, 1, 1, device=DEV)
+    db = torch.empty(3, device=DEV)
+    dx = ops.head_bwd(dv.to(DEV), nhwc(a, dtype), hw.detach().to(DEV), dw, db)
+    assert relerr(nchw(dx), av.grad) < tol_act(dtype)
+    assert relerr(dw.cpu(), hw.grad) < 1e-4
+    assert relerr(db.cpu(), hb.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(12, 10), (13, 9)])
+def test_bn_relu_pool_forward_backward(dtype, hw):
+    """conv-output -> BN(train) -> ReLU -> {skip gradient, MaxPool2d(2)} against autograd on the CPU."""
+    from oracle import unet_oracle as O
+    from stain2stain_amd import ops
+    H, W = hw
+    B, C = 2, 16
+    g = torch.Generator().manual_seed(12)
+    z = rnd(torch.rand(B, C, H, W, generator=g) * 4 - 2, dtype).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.rand(C, generator=g) - 0.5).requires_grad_(True)
+    y, mean, var = O.batchnorm_train(z, gamma, beta)
+    y = y.clamp_min(0)
+    if dtype == torch.bfloat16:   # the kernel stores y in bf16 and pools the stored value
+        y = y + (y.detach().to(dtype).float() - y.detach())
+    p = O.maxpool2(y)
+    g1 = rnd(torch.rand(y.shape, generator=g) - 0.5, dtype)
+    gp = rnd(torch.rand(p.shape, generator=g) - 0.5, dtype)
+    ((y * g1).sum() + (p * gp).sum()).backward()
+
+    zs = nhwc(z.detach(), dtype)
+    n = B * H * W
+    stat = torch.stack([zs.float().sum((0, 1, 2)), (zs.float() ** 2).sum((0, 1, 2))])[None].contiguous()
+    rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV); nb = torch.zeros((), dtype=torch.int64, device=DEV)
+    st = ops.bn_finalize(stat, n, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv, nb)
+    assert relerr(st[0].cpu(), mean) < 1e-5
+    assert relerr(st[1].cpu(), torch.rsqrt(var + 1e-5)) < 1e-5
+    assert relerr(rm.cpu(), 0.1 * mean) < 1e-5
+    assert relerr(rv.cpu(), 0.9 + 0.1 * var * n / (n - 1)) < 1e-5
+    assert int(nb) == 1
+    ya, pool = ops.bn_relu_apply(zs, st[2], st[3], want_pool=True)
+    assert relerr(nchw(ya), y) < tol_act(dtype)
+    assert relerr(nchw(pool), p) < tol_act(dtype)
+    dgam = torch.empty(C, device=DEV); dbet = torch.empty(C, device=DEV); dbias = torch.empty(C, device=DEV)
+    dz = ops.bn_relu_bwd(nhwc(g1, dtype), nhwc(gp, dtype), ya, zs, st, gamma.detach().to(DEV), dgam, dbet, dbias)
+    assert relerr(nchw(dz), z.grad) < tol_act(dtype) * 2
+    assert relerr(dgam.cpu(), gamma.grad) < 5e-3 if dtype == torch.bfloat16 else relerr(dgam.cpu(), gamma.grad) < 1e-4
+    assert relerr(dbet.cpu(), beta.grad) < 5e-3 if dtype == torch.bfloat16 else relerr(dbet.cpu(), beta.grad) < 1e-4
+    assert float(dbias.abs().max()) < 1e-2 * float(z.grad.abs().sum((0, 2, 3)).max())  # analytically zero
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_fwd_bwd_with_pad_and_bias(dtype):
+    from oracle import unet_oracle as O
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, C, h, w = 2, 16, 5, 6
+    Ho, Wo = 11, 13
+    x = rnd(torch.rand(B, C, h, w, generator=g) * 2 - 1, dtype).requires_grad_(True)
+    bias = (torch.rand(B, C, generator=g) - 0.5).requires_grad_(True)
+    up = O.upsample2x_bilinear_ac(x + bias[:, :, None, None])
+    up = F.pad(up, [(Wo - 2 * w) // 2, Wo - 2 * w - (Wo - 2 * w) // 2, (Ho - 2 * h) // 2, Ho - 2 * h - (Ho - 2 * h) // 2])
+    gy = rnd(torch.rand(up.shape, generator=g) - 0.5, dtype)
+    (up * gy).sum().backward()
+    buf = torch.zeros(B, Ho, Wo, C + 8, device=DEV, dtype=dtype)
+    ops.upsample2x_fwd(nhwc(x.detach(), dtype), buf[..., 8:], bias.detach().to(DEV))
+    assert relerr(nchw(buf[..., 8:]), up) < tol_act(dtype)
+    assert float(buf[..., :8].abs().max()) == 0.0
+    gbuf = torch.zeros(B, Ho, Wo, C + 8, device=DEV, dtype=dtype)
+    gbuf[..., 8:] = nhwc(gy, dtype)
+    dx = ops.upsample2x_bwd(gbuf[..., 8:], h, w)
+    assert relerr(nchw(dx), x.grad) < tol_act(dtype)
+    assert relerr(ops.pixel_sum(dx).cpu(), bias.grad) < tol_act(dtype)
+
+
+def test_time_path_and_loss():
+    from oracle import unet_oracle as O
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(14)
+    t = torch.rand(5, generator=g)
+    assert relerr(ops.time_embedding(t.to(DEV), 32).cpu(), O.time_embedding(t, 32)) < 1e-6
+    assert relerr(ops.time_embedding(t.to(DEV), 256).cpu(), O.time_embedding(t, 256)) < 1e-6
+    x = torch.rand(5, 32, generator=g, requires_grad=True)
+    w = (torch.rand(48, 32, generator=g) - 0.5).requires_grad_(True)
+    b = (torch.rand(48, generator=g) - 0.5).requires_grad_(True)
+    h = x @ w.t() + b
+    a = h * torch.sigmoid(h)
+    da = torch.rand(a.shape, generator=g) - 0.5
+    (a * da).sum().backward()
+    hg = ops.linear_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV))
+    assert relerr(hg.cpu(), h) < 1e-6
+    ag = ops.silu_fwd(hg)
+    assert relerr(ag.cpu(), a) < 1e-6
+    dh = ops.silu_bwd(hg, da.to(DEV))
+    dw = torch.empty(48, 32, device=DEV); db = torch.empty(48, device=DEV)
+    dx = ops.linear_bwd(dh, x.detach().to(DEV), w.detach().to(DEV), dw, db)
+    assert relerr(dx.cpu(), x.grad) < 1e-5
+    assert relerr(dw.cpu(), w.grad) < 1e-5
+    assert relerr(db.cpu(), b.grad) < 1e-5
+    # probability path + loss
+    x0 = torch.rand(3, 3, 8, 12, generator=g) * 2 - 1
+    x1 = torch.rand(3, 3, 8, 12, generator=g) * 2 - 1
+    tt = torch.rand(3, generator=g)
+    xt_ref, ut_ref = O.cfm_sample(x0, x1, tt)
+    xt, ut = ops.cfm_sample(x0.to(DEV), x1.to(DEV), tt.to(DEV))
+    assert relerr(xt.cpu(), xt_ref) < 1e-6 and relerr(ut.cpu(), ut_ref) < 1e-6
+    v = torch.rand(x0.shape, generator=g, requires_grad=True)
+    loss_ref = O.cfm_loss(v, ut_ref)
+    loss_ref.backward()
+    loss, dv = ops.mse_loss(v.detach().to(DEV), ut)
+    assert relerr(loss.cpu(), loss_ref) < 1e-6
+    assert relerr(dv.cpu(), v.grad) < 1e-6
+
+
+def test_adam_matches_torch_optim():
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(15)
+    p = torch.nn.Parameter(torch.rand(1000, generator=g) - 0.5)
+    opt = torch.optim.Adam([p], lr=1e-3, weight_decay=1e-2)
+    pg = p.detach().clone().to(DEV)
+    m = torch.zeros_like(pg); v = torch.zeros_like(pg)
+    for step in range(1, 4):
+        gr = torch.rand(1000, generator=g) - 0.5
+        p.grad = gr.clone()
+        opt.step()
+        ops.adam_step_(pg, gr.to(DEV), m, v, step, 1e-3, weight_decay=1e-2)
+        assert relerr(pg.cpu(), p.detach()) < 1e-6
+
+
+def test_layout_roundtrip_and_error_status():
+    from stain2stain_amd import ops
+    x = torch.rand(2, 16, 5, 7)
+    for dt in (torch.float32, torch.bfloat16):
+        y = ops.nchw_to_nhwc(x.to(DEV), dt)
+        assert relerr(nchw(y), rnd(x, dt)) == 0.0
+        assert relerr(ops.nhwc_to_nchw(y).cpu(), rnd(x, dt)) == 0.0
+    with pytest.raises(RuntimeError):   # channel count not a multiple of 8 -> negative status -> exception
+        ops.nchw_to_nhwc(torch.rand(1, 12, 4, 4, device=DEV), torch.float32)
