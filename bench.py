@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paired 256x256 stain tiles/s for one full optimisation step of the
+flow-matching U-Net (sample -> forward -> loss -> backward -> gradient all-reduce -> Adam).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] as mapped by SURVEY.md section 8(d); the reference has no pix2pix
+G+D, its stain models are all conditional flow matching): production U-Net
+features [64,128,256,512,1024], 3x256x256 tiles, batch 16 per GPU, bf16 MFMA compute with fp32
+accumulation / BatchNorm statistics / master weights, synthetic tiles U(-1,1), random-init weights.
+Weak scaling: every rank steps its own 16 tiles; the only collective is the gradient all-reduce.
+
+One JSON line on rank 0; see README / DESIGN.md for the roofline and cpu_baseline objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FEATURES = [64, 128, 256, 512, 1024]
+TILE = 256
+BATCH_PER_GPU = 16
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The CPU oracle (a port of the reference's torch path) timed on this box's host cores."""
+    from oracle import unet_oracle as O
+    from stain2stain_amd import FlowUNet
+    torch.manual_seed(1984)
+    P = {k: v.detach().clone() for k, v in FlowUNet(3, FEATURES, 3, 256).state_dict().items()}
+    g = torch.Generator().manual_seed(1984)
+    b = 2
+    x0 = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
+    x1 = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
+    t = torch.rand(b, generator=g)
+    threads = torch.get_num_threads()
+    O.train_steps(P, [(x0, x1, t)])          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_steps(P, [(x0, x1, t)])
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 4 or el > seconds_budget:
+            break
+    return {"value": round(b * n / el, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"same U-Net and step (fwd+bwd+Adam, fp32) at batch {b}, 1 warm-up + {n} timed steps, "
+                      f"torch {torch.__version__} CPU, {threads} threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (default: the headline 16)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from stain2stain_amd import CFMTrainer, FlowUNet, ops
+
+    torch.manual_seed(1984)
+    net = FlowUNet(3, FEATURES, 3, 256, precision=args.precision).to(dev).train()
+    trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(1984 + rank)
+    B = args.batch
+    x0 = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
+    x1 = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
+    ts = [torch.rand(B, generator=g).to(dev) for _ in range(args.warmup + args.steps)]
+
+    for i in range(args.warmup):
+        trainer.step(x0, x1, ts[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = trainer.step(x0, x1, ts[args.warmup + i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el)
+
+    if rank == 0:
+        # per-kernel time from the HIP events recorded around every launch of the timed region
+        agg = {}
+        for name, work, e0, e1 in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += work
+        dom = "conv3x3_mfma"          # forward + data-gradient implicit-GEMM kernel
+        n_l, t_l, f_l = agg[dom]
+        achieved = f_l / t_l / 1e12
+        kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / args.steps, 4),
+                       **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {})}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        out = {
+            "metric": "paired 256x256 stain tiles/sec (full CFM optimisation step)",
+            "value": round(B * world * args.steps / elapsed, 3),
+            "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "CFM U-Net [64,128,256,512,1024] 3x256x256 H&E->IHC tiles, "
+                                   f"batch {B}/GPU, sample+fwd+loss+bwd+allreduce+Adam",
+                       "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
+                       "final_loss": round(float(loss), 6)},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fwd + dgrad launches)",
+                         "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_l // args.steps,
+                         "avg_launch_ms": round(t_l * 1e3 / n_l, 4),
+                         "algorithmic_gflop_per_launch": round(f_l / n_l / 1e9, 3)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

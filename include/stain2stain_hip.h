@@ -11,7 +11,7 @@
  *   - all pointers are DEVICE pointers unless stated otherwise; the caller owns every buffer,
  *     kernels never allocate; `stream` is a hipStream_t passed as void*
  *   - dtype: S2S_BF16 (0) = bf16 tensors, bf16 MFMA, fp32 accumulate;
- *            S2S_F32 (1)  = fp32 tensors; MFMA products formed from a hi/lo bf16 split (3 MFMAs)
+ *            S2S_F32 (1)  = fp32 tensors; MFMA products formed from a 3-way bf16 split (6 MFMAs, fp32-grade)
  *   - activation tensors are NHWC "views": element (n,h,w,c) lives at base[((n*H+h)*W+w)*ld + c];
  *     ld (pixel stride, elements) lets a channel slice of a wider buffer be used in place.
  *     Channel counts and ld must be multiples of 8, base pointers 16-byte aligned.
@@ -43,7 +43,7 @@ extern "C" {
  * (sum, sum of squares) of the stored values per output channel, for BatchNorm.  ep_scale/ep_shift
  * (optional, both or neither) and relu: y = relu?((acc + bias) * scale + shift) -- eval-mode BatchNorm
  * folded into the epilogue. */
-int s2s_conv3x3_stat_blocks(int B, int H, int W, int Cout);
+int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout);
 int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
                      const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
                      const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W, int Cout,
@@ -64,7 +64,7 @@ int s2s_stem_stat_blocks(int B, int H, int W);
 int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
                          float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream);
 int s2s_stem_wgrad_blocks(int B, int H, int W);
-/* part: float[blocks][Cout][Cin*9+1]; dbias may be NULL */
+/* part: float[2*blocks][Cout][32]; Cin*9 <= 31; dbias may be NULL */
 int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part, float* dw_oihw,
                            float* dbias, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
 int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float* y_nchw, int B,

@@ -1,0 +1,12 @@
+"""stain2stain_amd -- the stain-to-stain flow-matching hot path on MI355X (gfx950).
+
+Drop-in replacements for the reference's torch-only network components (same signatures and
+state_dict keys), computed by hand-written HIP kernels behind a C ABI
+(include/stain2stain_hip.h, stain2stain_amd/csrc/*.hip).  HIP only: there is no CPU fallback.
+"""
+from .components import FlowMatchingDecoder, FlowUNet, SharedEncoder, TimeEmbedding
+from .flow_matching import ConditionalFlowMatcher, ConditionalFlowMatchingModule, euler_generate
+from .trainer import CFMTrainer
+
+__all__ = ["SharedEncoder", "FlowMatchingDecoder", "TimeEmbedding", "FlowUNet", "ConditionalFlowMatcher",
+           "ConditionalFlowMatchingModule", "euler_generate", "CFMTrainer"]

@@ -22,9 +22,11 @@
 //     decoder's torch.cat([skip, up], dim=1) (task_decoders.py:49) without materialising the cat.
 //
 // T = bf16: operands are staged as they are (throughput mode).
-// T = float ("split" mode): every fp32 operand is staged as hi = bf16(x), lo = bf16(x - hi) and each
-//   product is formed as hi*hi + hi*lo + lo*hi on the same MFMA path (about 2^-17 relative product
-//   error, fp32 accumulation).  This is the parity mode that is checked against the fp32 oracle.
+// T = float ("split" mode): every fp32 operand is staged as three bf16 images h = bf16(x),
+//   m = bf16(x - h), l = bf16(x - h - m) (24 mantissa bits in total) and each product is formed on the
+//   same MFMA path from the six partial products of order <= 2^-18 (hh, hm, mh, hl, lh, mm), smallest
+//   first, fp32 accumulation: fp32-grade products at 6/16 of the cost of the f32 MFMA.  This is the
+//   parity mode that is checked against the fp32 oracle.
 #include "common.h"
 #include <type_traits>
 
@@ -54,7 +56,7 @@ template <> struct Piece<bf16_t> {
     for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
   }
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
-  __device__ __forceinline__ void to_lds(char* hi, char* /*lo*/, int off) const {
+  __device__ __forceinline__ void to_lds(char* hi, int /*img_stride*/, int off) const {
     *reinterpret_cast<bf16x8*>(hi + off) = v;
   }
 };
@@ -68,24 +70,26 @@ template <> struct Piece<float> {
     a = *reinterpret_cast<const f32x4*>(p);
     b = *reinterpret_cast<const f32x4*>(p + 4);
   }
-  __device__ __forceinline__ void to_lds(char* hi, char* lo, int off) const {
-    bf16x8 h, l;
+  __device__ __forceinline__ void to_lds(char* hi, int img_stride, int off) const {
+    bf16x8 h, m, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h[i] = (bf16_t)a[i];
-      l[i] = (bf16_t)(a[i] - (float)h[i]);
-      h[4 + i] = (bf16_t)b[i];
-      l[4 + i] = (bf16_t)(b[i] - (float)h[4 + i]);
+    for (int i = 0; i < 8; ++i) {
+      const float x = i < 4 ? a[i] : b[i - 4];
+      h[i] = (bf16_t)x;
+      const float r1 = x - (float)h[i];
+      m[i] = (bf16_t)r1;
+      l[i] = (bf16_t)(r1 - (float)m[i]);
     }
     *reinterpret_cast<bf16x8*>(hi + off) = h;
-    *reinterpret_cast<bf16x8*>(lo + off) = l;
+    *reinterpret_cast<bf16x8*>(hi + img_stride + off) = m;
+    *reinterpret_cast<bf16x8*>(hi + 2 * img_stride + off) = l;
   }
 };
 
 template <typename T, int TH, int TW, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr bool SPLIT = std::is_same<T, float>::value;
-  constexpr int NIMG = SPLIT ? 2 : 1;
+  constexpr int NIMG = SPLIT ? 3 : 1;
   constexpr int HW_ = TW + 2, HH_ = TH + 2, HALO = HW_ * HH_;
   constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int idx = tid + i * 256;
-      if (idx < A_PIECES) hreg[i].to_lds(hi, hi + A_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
+      if (idx < A_PIECES) hreg[i].to_lds(hi, A_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
     }
   };
   auto load_w = [&](int it) {
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int idx = tid + i * 256;
-      if (idx < B_PIECES) wreg[i].to_lds(hi, hi + B_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
+      if (idx < B_PIECES) wreg[i].to_lds(hi, B_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
     }
   };
 
@@ -216,19 +220,26 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
         for (int ni = 0; ni < NI; ++ni)
           bfr[ni] = *reinterpret_cast<const bf16x8*>(Bhi + bbase[ni] + ks * 32);
         if constexpr (SPLIT) {
-          bf16x8 al[MI], bl[NI];
+          bf16x8 am[MI], al[MI], bm[NI], bl[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            al[mi] = *reinterpret_cast<const bf16x8*>(Ahi + A_BYTES + abase[mi] + tapoff + ks * 32);
+          for (int mi = 0; mi < MI; ++mi) {
+            am[mi] = *reinterpret_cast<const bf16x8*>(Ahi + A_BYTES + abase[mi] + tapoff + ks * 32);
+            al[mi] = *reinterpret_cast<const bf16x8*>(Ahi + 2 * A_BYTES + abase[mi] + tapoff + ks * 32);
+          }
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            bl[ni] = *reinterpret_cast<const bf16x8*>(Bhi + B_BYTES + bbase[ni] + ks * 32);
+          for (int ni = 0; ni < NI; ++ni) {
+            bm[ni] = *reinterpret_cast<const bf16x8*>(Bhi + B_BYTES + bbase[ni] + ks * 32);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(Bhi + 2 * B_BYTES + bbase[ni] + ks * 32);
+          }
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm[ni], acc[mi][ni], 0, 0, 0);
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bm[ni], acc[mi][ni], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 
 template <typename T, int TH, int TW, int BN, int WM, int WN>
 int launch_cfg(Conv3x3Args& a, hipStream_t s) {
-  constexpr int NIMG = std::is_same<T, float>::value ? 2 : 1;
+  constexpr int NIMG = std::is_same<T, float>::value ? 3 : 1;
   constexpr int lds = 2 * NIMG * ((TH + 2) * (TW + 2) + BN) * ROWB;
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
@@ -318,8 +329,24 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
+// tile geometry of one launch; s2s_conv3x3_stat_blocks must agree with it
+template <typename T> struct Geo;
+template <> struct Geo<bf16_t> { static constexpr int TH = 8, TW = 32, NTH = 16, NTW = 16; };
+template <> struct Geo<float> { static constexpr int TH = 4, TW = 32, NTH = 8, NTW = 16; };
+
 template <typename T>
-int dispatch(Conv3x3Args& a, hipStream_t s) {
+int dispatch(Conv3x3Args& a, hipStream_t s);
+
+template <>
+int dispatch<float>(Conv3x3Args& a, hipStream_t s) {
+  // three bf16 images per operand: smaller tiles so the double-buffered LDS still fits
+  if (a.W <= 16) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
+  return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
+}
+
+template <>
+int dispatch<bf16_t>(Conv3x3Args& a, hipStream_t s) {
+  using T = bf16_t;
   const bool narrow = a.W <= 16;
   if (a.Cout <= 64) {
     if (narrow) return launch_cfg<T, 16, 16, 64, 4, 1>(a, s);
@@ -333,11 +360,18 @@ int dispatch(Conv3x3Args& a, hipStream_t s) {
 
 // Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
 // (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.
-extern "C" int s2s_conv3x3_stat_blocks(int B, int H, int W, int Cout) {
+extern "C" int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout) {
   (void)Cout;
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
-  if (W <= 16) return B * cdiv(H, 16) * cdiv(W, 16);
-  return B * cdiv(H, 8) * cdiv(W, 32);
+  if (dtype == S2S_BF16) {
+    if (W <= 16) return B * cdiv(H, Geo<bf16_t>::NTH) * cdiv(W, Geo<bf16_t>::NTW);
+    return B * cdiv(H, Geo<bf16_t>::TH) * cdiv(W, Geo<bf16_t>::TW);
+  }
+  if (dtype == S2S_F32) {
+    if (W <= 16) return B * cdiv(H, Geo<float>::NTH) * cdiv(W, Geo<float>::NTW);
+    return B * cdiv(H, Geo<float>::TH) * cdiv(W, Geo<float>::TW);
+  }
+  return S2S_ERR_DTYPE;
 }
 
 extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,

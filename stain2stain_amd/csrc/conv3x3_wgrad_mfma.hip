@@ -17,7 +17,7 @@
 //   * split-K over pixel tiles: blockIdx.z walks tiles z, z+S, ...; partial sums go to
 //     part[S][9][Cout][Cin] (fp32) and s2s_conv3x3_wgrad_reduce folds them, deterministically, into
 //     the OIHW fp32 gradient the optimiser sees.
-//   * T = float: hi/lo bf16 split of both operands, 3 MFMAs per product (see conv3x3_mfma.hip).
+//   * T = float: three-way bf16 split of both operands, 6 MFMAs per product (see conv3x3_mfma.hip).
 #include "common.h"
 #include <type_traits>
 
@@ -40,7 +40,7 @@ template <> struct WPiece<bf16_t> {
     for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
   }
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
-  __device__ __forceinline__ void to_lds(char* hi, char*, int off) const { *reinterpret_cast<bf16x8*>(hi + off) = v; }
+  __device__ __forceinline__ void to_lds(char* hi, int, int off) const { *reinterpret_cast<bf16x8*>(hi + off) = v; }
 };
 template <> struct WPiece<float> {
   f32x4 a, b;
@@ -52,17 +52,19 @@ template <> struct WPiece<float> {
     a = *reinterpret_cast<const f32x4*>(p);
     b = *reinterpret_cast<const f32x4*>(p + 4);
   }
-  __device__ __forceinline__ void to_lds(char* hi, char* lo, int off) const {
-    bf16x8 h, l;
+  __device__ __forceinline__ void to_lds(char* hi, int img_stride, int off) const {
+    bf16x8 h, m, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h[i] = (bf16_t)a[i];
-      l[i] = (bf16_t)(a[i] - (float)h[i]);
-      h[4 + i] = (bf16_t)b[i];
-      l[4 + i] = (bf16_t)(b[i] - (float)h[4 + i]);
+    for (int i = 0; i < 8; ++i) {
+      const float x = i < 4 ? a[i] : b[i - 4];
+      h[i] = (bf16_t)x;
+      const float r1 = x - (float)h[i];
+      m[i] = (bf16_t)r1;
+      l[i] = (bf16_t)(r1 - (float)m[i]);
     }
     *reinterpret_cast<bf16x8*>(hi + off) = h;
-    *reinterpret_cast<bf16x8*>(lo + off) = l;
+    *reinterpret_cast<bf16x8*>(hi + img_stride + off) = m;
+    *reinterpret_cast<bf16x8*>(hi + 2 * img_stride + off) = l;
   }
 };
 
@@ -82,7 +84,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p_rows0, int row_stride4) 
 template <typename T, int TH, int TW>
 __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr bool SPLIT = std::is_same<T, float>::value;
-  constexpr int NIMG = SPLIT ? 2 : 1;
+  constexpr int NIMG = SPLIT ? 3 : 1;
   constexpr int NPX = TH * TW;                 // 128
   constexpr int HW_ = TW + 2, HALO = (TH + 2) * HW_;
   constexpr int DY_BYTES = 2 * NPX * 64;       // two 32-channel images
@@ -154,14 +156,14 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
       const int idx = tid + i * 256;
       const int px = idx >> 3, pc = idx & 7;
       if (idx < DY_PIECES)
-        dreg[i].to_lds(ldsDY, ldsDY + DY_BYTES, (pc >> 2) * (NPX * 64) + px * 64 + (pc & 3) * 16);
+        dreg[i].to_lds(ldsDY, DY_BYTES, (pc >> 2) * (NPX * 64) + px * 64 + (pc & 3) * 16);
     }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int idx = tid + i * 256;
       const int px = idx >> 3, pc = idx & 7;
       if (idx < X_PIECES)
-        xreg[i].to_lds(ldsX, ldsX + X_BYTES, (pc >> 2) * (HALO * 64) + px * 64 + (pc & 3) * 16);
+        xreg[i].to_lds(ldsX, X_BYTES, (pc >> 2) * (HALO * 64) + px * 64 + (pc & 3) * 16);
     }
   };
 
@@ -180,16 +182,23 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
       const int m0 = ks * 16;
       const int py = m0 / TW, px = m0 - py * TW;
       const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
-      bf16x8 al;
-      if constexpr (SPLIT) al = tr_frag(Ahi + DY_BYTES + m0 * 64, 4 * 64);
+      bf16x8 am, al;
+      if constexpr (SPLIT) {
+        am = tr_frag(Ahi + DY_BYTES + m0 * 64, 4 * 64);
+        al = tr_frag(Ahi + 2 * DY_BYTES + m0 * 64, 4 * 64);
+      }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int hoff = ((py + tap / 3) * HW_ + px + tap % 3) * 64;
         const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
         if constexpr (SPLIT) {
-          const bf16x8 bl = tr_frag(Bhi + X_BYTES + hoff, 4 * 64);
+          const bf16x8 bm = tr_frag(Bhi + X_BYTES + hoff, 4 * 64);
+          const bf16x8 bl = tr_frag(Bhi + 2 * X_BYTES + hoff, 4 * 64);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[tap], 0, 0, 0);
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr, acc[tap], 0, 0, 0);
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bl, acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bfr, acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bm, acc[tap], 0, 0, 0);
         }
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
       }
@@ -228,7 +237,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 
 template <typename T, int TH, int TW>
 int launch_wgrad(WgradArgs& a, hipStream_t s) {
-  constexpr int NIMG = std::is_same<T, float>::value ? 2 : 1;
+  constexpr int NIMG = std::is_same<T, float>::value ? 3 : 1;
   constexpr int lds = NIMG * (2 * TH * TW * 64 + 2 * (TH + 2) * (TW + 2) * 64);
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);

@@ -79,82 +79,155 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// stem weight / bias gradient:  dW[co][ci][tap] = sum_p dY[p][co] * x[p (+) tap][ci],  db[co] = sum_p dY[p][co]
-// One workgroup walks 8x16 pixel tiles; thread = (co mod 64, column group); dY through LDS, the
-// image halo through LDS (broadcast reads).  part[gridDim.x][Cout][Cin*9+1].
+// stem weight / bias gradient on MFMA:
+//   D[co][k] = sum_p dY[p][co] * P[p][k],  k = ci*9 + tap (Cin*9 <= 31 columns used), P[p][Cin*9] = 1 (bias)
+// One workgroup walks 16x16 pixel tiles.  dY is staged as [pixel][32 co] images and the im2col patch
+// P as a [pixel][32 k] image (built in LDS from the fp32 halo), both read with ds_read_b64_tr_b16 exactly
+// like conv3x3_wgrad_mfma.hip.  Wave w owns output channels 32*(w&1).. and the pixel half (w>>1) of
+// every tile; partial slabs part[2*gridDim.x][Cout][32] are folded by stem_wgrad_reduce_kernel.
+// T = float: three-way bf16 split of both operands, six MFMAs (see conv3x3_mfma.hip).
 // ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag8(const char* p) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 64));
+  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = l4[i]; r[4 + i] = h4[i]; }
+  return r;
+}
+
+template <int NIMG>
+__device__ __forceinline__ void split_store(char* base, int img_stride, int off, const float* v8) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = (bf16_t)v8[i];
+    const float r1 = v8[i] - (float)h[i];
+    m[i] = (bf16_t)r1;
+    l[i] = (bf16_t)(r1 - (float)m[i]);
+  }
+  *reinterpret_cast<bf16x8*>(base + off) = h;
+  if (NIMG == 3) {
+    *reinterpret_cast<bf16x8*>(base + img_stride + off) = m;
+    *reinterpret_cast<bf16x8*>(base + 2 * img_stride + off) = l;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ dy, int lddy,
                                                          const float* __restrict__ x, float* __restrict__ part,
                                                          int B, int H, int W, int Cin, int Cout, int tilesY,
                                                          int tilesX) {
-  __shared__ float dyl[128][65];                        // [pixel][co] (+1 pad)
-  __shared__ float xl[STEM_MAX_CIN][10][18];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int K = Cin * 9 + 1;                             // +1: bias column
-  const int kper = (K + 3) / 4;                          // columns per thread group
-  const int k_begin = grp * kper;
+  constexpr int NIMG = sizeof(T) == 4 ? 3 : 1;
+  constexpr int NPX = 256;
+  constexpr int DY_IMG = 2 * NPX * 64;      // two 32-channel images of 64-B rows
+  constexpr int P_IMG = NPX * 64;           // [pixel][32 k]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsDY = smem;                                  // [NIMG][2][256][64B]
+  char* const ldsP = smem + NIMG * DY_IMG;                   // [NIMG][256][64B]
+  float* const xl = reinterpret_cast<float*>(ldsP + NIMG * P_IMG);  // [Cin][18][18]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave & 1, whalf = wave >> 1;
+  const int co0 = blockIdx.y * 64;
+  const int K = Cin * 9;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + pq * 4) * 2;
   const int ntiles = B * tilesY * tilesX;
-  for (int cb = 0; cb < Cout; cb += 64) {
-    float acc[(STEM_MAX_CIN * 9 + 1 + 3) / 4];
+  f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) acc[i] = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      int bt = tile;
-      const int tx = bt % tilesX; bt /= tilesX;
-      const int ty = bt % tilesY;
-      const int n = bt / tilesY;
-      const int y0 = ty * 8, x0 = tx * 16;
-      __syncthreads();
-      for (int i = threadIdx.x; i < 128 * 64; i += 256) {
-        const int pp = i >> 6, c = i & 63;
-        const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
-        dyl[pp][c] = (gy < H && gx < W && cb + c < Cout)
-                         ? to_f32(dy[(((long)n * H + gy) * W + gx) * lddy + cb + c]) : 0.f;
-      }
-      for (int i = threadIdx.x; i < Cin * 10 * 18; i += 256) {
-        const int ci = i / 180, r = i - ci * 180, hy = r / 18, hx = r - hy * 18;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        xl[ci][hy][hx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((long)n * Cin + ci) * H + gy) * W + gx] : 0.f;
-      }
-      __syncthreads();
-      for (int pp = 0; pp < 128; ++pp) {
-        const float g = dyl[pp][col];
-        const int py = pp >> 4, px = pp & 15;
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bt = tile;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int y0 = ty * 16, x0 = tx * 16;
+    __syncthreads();   // previous tile fully consumed
+    for (int i = tid; i < Cin * 324; i += 256) {
+      const int ci = i / 324, r = i - ci * 324, hy = r / 18, hx = r - hy * 18;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      xl[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((long)n * Cin + ci) * H + gy) * W + gx] : 0.f;
+    }
+    // dY tile: 256 px x 64 co = 2048 pieces of 8 channels
 #pragma unroll
-        for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) {
-          const int k = k_begin + i;
-          if (i < kper && k < K) {
-            float xv = 1.f;
-            if (k < K - 1) {
-              const int ci = k / 9, t = k - ci * 9;
-              xv = xl[ci][py + t / 3][px + t % 3];
-            }
-            acc[i] = fmaf(g, xv, acc[i]);
+    for (int it = 0; it < 8; ++it) {
+      const int idx = tid + it * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      const int gy = y0 + (px >> 4), gx = x0 + (px & 15), co = co0 + pc * 8;
+      float v8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v8[k] = 0.f;
+      if (gy < H && gx < W && co < Cout) {
+        const f32x8 v = load8(dy + (((long)n * H + gy) * W + gx) * lddy + co);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v8[k] = v.v[k];
+      }
+      split_store<NIMG>(ldsDY, DY_IMG, (pc >> 2) * (NPX * 64) + px * 64 + (pc & 3) * 16, v8);
+    }
+    __syncthreads();   // halo visible
+    {                  // im2col row of pixel `tid`: k = ci*9+tap, column K = 1 (bias), rest 0
+      const int py = tid >> 4, px = tid & 15;
+      const bool inside = (y0 + py < H) && (x0 + px < W);
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        float v8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int kk = c4 * 8 + k;
+          float v = 0.f;
+          if (kk < K) {
+            const int ci = kk / 9, t = kk - ci * 9;
+            v = xl[ci * 324 + (py + t / 3) * 18 + px + t % 3];
+          } else if (kk == K) {
+            v = inside ? 1.f : 0.f;   // dY is zero outside anyway
           }
+          v8[k] = v;
         }
+        split_store<NIMG>(ldsP, P_IMG, tid * 64 + c4 * 16, v8);
       }
     }
-    if (cb + col < Cout) {
+    __syncthreads();
+    const char* A0 = ldsDY + wco * (NPX * 64) + frag_off;
+    const char* B0 = ldsP + frag_off;
 #pragma unroll
-      for (int i = 0; i < (STEM_MAX_CIN * 9 + 1 + 3) / 4; ++i) {
-        const int k = k_begin + i;
-        if (i < kper && k < K) part[((long)blockIdx.x * Cout + cb + col) * K + k] = acc[i];
+    for (int ks = 0; ks < 8; ++ks) {
+      const int m0 = (whalf * 8 + ks) * 16;
+      const bf16x8 ah = tr_frag8(A0 + m0 * 64);
+      const bf16x8 bh = tr_frag8(B0 + m0 * 64);
+      if constexpr (NIMG == 3) {
+        const bf16x8 am = tr_frag8(A0 + DY_IMG + m0 * 64), al = tr_frag8(A0 + 2 * DY_IMG + m0 * 64);
+        const bf16x8 bm = tr_frag8(B0 + P_IMG + m0 * 64), bl = tr_frag8(B0 + 2 * P_IMG + m0 * 64);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
       }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     }
+  }
+  // D[co][k]: column = lane&31 = k, rows = co
+  const int kcol = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+    if (co < Cout) part[(((long)blockIdx.x * 2 + whalf) * Cout + co) * 32 + kcol] = acc[j];
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int Cin, float* dw, float* db,
+__global__ void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
                                          int accumulate) {
-  const int K = Cin * 9 + 1;
+  const int K = Cin * 9;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cout * K) return;
-  const int co = i / K, k = i - co * K;
+  if (i >= Cout * 32) return;
+  const int co = i >> 5, k = i & 31;
+  if (k > K || (k == K && !db)) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * Cout * K + i];
-  float* dst = (k < K - 1) ? dw + co * (K - 1) + k : db + co;
-  if (k == K - 1 && !db) return;
+  for (int b = 0; b < nslab; ++b) s += (double)part[(long)b * Cout * 32 + i];
+  float* dst = (k < K) ? dw + co * K + k : db + co;
   *dst = accumulate ? *dst + (float)s : (float)s;
 }
 
@@ -307,29 +380,38 @@ extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float*
 
 extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
-  const int nt = B * cdiv(H, 8) * cdiv(W, 16);
-  return nt < 1024 ? nt : 1024;
+  const int nt = B * cdiv(H, 16) * cdiv(W, 16);
+  return nt < 512 ? nt : 512;
 }
 
-// part: float[blocks][Cout][Cin*9+1]
+// part: float[2*blocks][Cout][32]
 extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part,
                                       float* dw_oihw, float* dbias, int accumulate, int B, int H, int W, int Cin,
                                       int Cout, void* stream) {
   if (!dy || !x_nchw || !part || !dw_oihw) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > STEM_MAX_CIN || Cout <= 0 || (Cout % 8) || (lddy % 8))
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin * 9 > 31 || Cout <= 0 || (Cout % 8) || (lddy % 8))
     return S2S_ERR_SHAPE;
   const int nb = s2s_stem_wgrad_blocks(B, H, W);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dy, lddy, x_nchw, part, B,
-                       H, W, Cin, Cout, cdiv(H, 8), cdiv(W, 16));
-  else if (dtype == S2S_F32)
-    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dy, lddy, x_nchw, part, B, H,
-                       W, Cin, Cout, cdiv(H, 8), cdiv(W, 16));
-  else return S2S_ERR_DTYPE;
-  const int n = Cout * (Cin * 9 + 1);
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, part, nb, Cout, Cin, dw_oihw,
-                     dbias, accumulate);
+  dim3 grid(nb, cdiv(Cout, 64));
+  if (dtype == S2S_BF16) {
+    const int lds = 1 * (2 * 256 * 64 + 256 * 64) + Cin * 324 * 4;
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, lddy, x_nchw, part, B,
+                       H, W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
+  } else if (dtype == S2S_F32) {
+    const int lds = 3 * (2 * 256 * 64 + 256 * 64) + Cin * 324 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<float>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return S2S_ERR_LAUNCH;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, lddy, x_nchw, part, B, H,
+                       W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
+  } else return S2S_ERR_DTYPE;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(Cout * 32, 256)), dim3(256), 0, s, part, 2 * nb, Cout, Cin,
+                     dw_oihw, dbias, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

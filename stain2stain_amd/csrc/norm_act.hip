@@ -23,17 +23,17 @@ constexpr int RED_ROWS = 8;  // pixel groups per workgroup in the reduction kern
 // ---------------------------------------------------------------------------------------------
 // statistics finalize
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long* num_batches, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* scale_out,
                                    float* shift_out) {
-  __shared__ double s1[8][32], s2[8][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  __shared__ double s1[32][33], s2[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 channels x 32 row groups
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int i = rg; i < nblk; i += 8) {
+    for (int i = rg; i < nblk; i += 32) {
       a += (double)part[((long)i * 2 + 0) * C + c];
       b += (double)part[((long)i * 2 + 1) * C + c];
     }
@@ -41,7 +41,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int
   s2[rg][cl] = b;
   __syncthreads();
   if (rg == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+    for (int k = 1; k < 32; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
     const double mean = a / count;
     double var = b / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -203,21 +203,30 @@ struct WindowGrad {
   }
 };
 
-// partial[blk][2][C]: sum dz, sum dz*xhat.  grid = (C/32 rounded up, nblk); 256 threads = 4 channel
-// pieces x 64 window groups.
+// Thread layout of the two backward kernels: a workgroup covers PCB channel pieces (8 channels each,
+// PCB = min(32, pow2 >= C/8)) x WL = 256/PCB window slots, piece index fastest across lanes, so a wave
+// reads whole NHWC pixel rows (full cache lines) instead of 32-channel slivers.
+__device__ __forceinline__ int pcb_of(int C) {
+  int p = 1;
+  while (p < 32 && p * 8 < C) p <<= 1;
+  return p;
+}
+
+// partial[blk][2][C]: sum dz, sum dz*xhat.  grid = (channel groups, nblk)
 template <typename T>
-__global__ void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
                                           const T* x, int ldx, const float* mean, const float* invstd,
                                           float* part, int B, int H, int W, int C) {
   const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;
   const long nwin = (long)B * Hw * Ww;
-  const int pc = threadIdx.x & 3, wl = threadIdx.x >> 2;   // 4 pieces (32 channels) x 64 windows
-  const int c8 = blockIdx.x * 32 + pc * 8;
+  const int PCB = pcb_of(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int c8 = (blockIdx.x * PCB + pc) * 8;
   float s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   if (c8 < C) {
-    for (long w = (long)blockIdx.y * 64 + wl; w < nwin; w += (long)gridDim.y * 64) {
+    for (long w = (long)blockIdx.y * WL + wl; w < nwin; w += (long)gridDim.y * WL) {
       long t = w;
       const int wx = (int)(t % Ww); t /= Ww;
       const int wy = (int)(t % Hw);
@@ -230,45 +239,55 @@ __global__ void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, in
         for (int k = 0; k < 8; ++k) { s1[k] += wg.dz[q][k]; s2[k] += wg.dz[q][k] * wg.xh[q][k]; }
     }
   }
-  __shared__ float red[2][64][33];
+  __shared__ float red[2][2304];
+  const int rowlen = PCB * 8 + 1;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { red[0][wl][pc * 8 + k] = s1[k]; red[1][wl][pc * 8 + k] = s2[k]; }
+  for (int k = 0; k < 8; ++k) { red[0][wl * rowlen + pc * 8 + k] = s1[k]; red[1][wl * rowlen + pc * 8 + k] = s2[k]; }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  for (int i = threadIdx.x; i < 2 * PCB * 8; i += 256) {
+    const int which = i / (PCB * 8), cl = i - which * (PCB * 8);
     float s = 0.f;
-    for (int r = 0; r < 64; ++r) s += red[which][r][cl];
-    const int c = blockIdx.x * 32 + cl;
+    for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
+    const int c = blockIdx.x * PCB * 8 + cl;
     if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = s;
   }
 }
 
 // sums partial[nblk][2][C] -> dgamma, dbeta (accumulate optional) and the two per-channel means
-__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
                                        float* dbeta, int accumulate, float* c1, float* c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double s1[32][33], s2[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblk; ++i) {
-    a += (double)part[((long)i * 2 + 0) * C + c];
-    b += (double)part[((long)i * 2 + 1) * C + c];
+  if (c < C)
+    for (int i = rg; i < nblk; i += 32) {
+      a += (double)part[((long)i * 2 + 0) * C + c];
+      b += (double)part[((long)i * 2 + 1) * C + c];
+    }
+  s1[rg][cl] = a;
+  s2[rg][cl] = b;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    for (int k = 1; k < 32; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+    dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+    c1[c] = (float)(a / count);
+    c2[c] = (float)(b / count);
   }
-  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
-  c1[c] = (float)(a / count);
-  c2[c] = (float)(b / count);
 }
 
 // dx = gamma*invstd*(dz - c1 - xhat*c2); optional partial sums of dx over pixels (conv-bias gradient)
 template <typename T>
-__global__ void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
                                          const T* x, int ldx, const float* mean, const float* invstd,
                                          const float* gamma, const float* c1, const float* c2, T* dx, int lddx,
                                          float* dxsum_part, int B, int H, int W, int C) {
   const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;
   const long nwin = (long)B * Hw * Ww;
-  const int pc = threadIdx.x & 3, wl = threadIdx.x >> 2;
-  const int c8 = blockIdx.x * 32 + pc * 8;
+  const int PCB = pcb_of(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int c8 = (blockIdx.x * PCB + pc) * 8;
   float s[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = 0.f;
@@ -276,7 +295,7 @@ __global__ void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int
     float ga[8], k1[8], k2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ga[k] = gamma[c8 + k] * invstd[c8 + k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k]; }
-    for (long w = (long)blockIdx.y * 64 + wl; w < nwin; w += (long)gridDim.y * 64) {
+    for (long w = (long)blockIdx.y * WL + wl; w < nwin; w += (long)gridDim.y * WL) {
       long t = w;
       const int wx = (int)(t % Ww); t /= Ww;
       const int wy = (int)(t % Hw);
@@ -298,26 +317,34 @@ __global__ void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int
     }
   }
   if (dxsum_part) {
-    __shared__ float red[64][33];
+    __shared__ float red[2304];
+    const int rowlen = PCB * 8 + 1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[wl][pc * 8 + k] = s[k];
+    for (int k = 0; k < 8; ++k) red[wl * rowlen + pc * 8 + k] = s[k];
     __syncthreads();
-    if (threadIdx.x < 32) {
+    for (int cl = threadIdx.x; cl < PCB * 8; cl += 256) {
       float t = 0.f;
-      for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
-      const int c = blockIdx.x * 32 + threadIdx.x;
+      for (int r = 0; r < WL; ++r) t += red[r * rowlen + cl];
+      const int c = blockIdx.x * PCB * 8 + cl;
       if (c < C) dxsum_part[(long)blockIdx.y * C + c] = t;
     }
   }
 }
 
 // out[c] (+)= sum_i part[i][c]
-__global__ void colsum_finalize_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
+  __shared__ double s1[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a = 0.0;
-  for (int i = 0; i < nblk; ++i) a += (double)part[(long)i * C + c];
-  out[c] = accumulate ? out[c] + (float)a : (float)a;
+  if (c < C)
+    for (int i = rg; i < nblk; i += 32) a += (double)part[(long)i * C + c];
+  s1[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    for (int k = 1; k < 32; ++k) a += s1[k][cl];
+    out[c] = accumulate ? out[c] + (float)a : (float)a;
+  }
 }
 
 inline int ew_grid(long total) {
@@ -327,11 +354,19 @@ inline int ew_grid(long total) {
   return (int)b;
 }
 
+inline int host_pcb(int C) {
+  int p = 1;
+  while (p < 32 && p * 8 < C) p <<= 1;
+  return p;
+}
+
+// partial rows per channel group: enough workgroups (~1536 in all) to fill 256 CUs a few times over
 inline int red_blocks(int B, int H, int W, int C) {
   const long nwin = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
-  long want = 2048 / cdiv(C, 32);
+  const int pcb = host_pcb(C), wl = 256 / pcb;
+  long want = 1536 / cdiv(C / 8, pcb);
   if (want < 1) want = 1;
-  long nb = (nwin + 63) / 64;
+  long nb = (nwin + wl - 1) / wl;
   if (nb > want) nb = want;
   if (nb < 1) nb = 1;
   return (int)nb;
@@ -345,7 +380,7 @@ extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, c
                                void* stream) {
   if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift) return S2S_ERR_NULL;
   if (nblk <= 0 || C <= 0 || count <= 0) return S2S_ERR_SHAPE;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, C,
                      (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
                      invstd, scale, shift);
   S2S_LAUNCH_CHECK();
@@ -421,11 +456,11 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   float* c2 = c1 + C;
   const double count = (double)B * H * W;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(cdiv(C, 32), nb);
+  dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
 #define S2S_BN_BWD(TT)                                                                                             \
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,     \
                      ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                  \
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, nb, C, count, dgamma,      \
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, nb, C, count, dgamma,      \
                      dbeta, accumulate, c1, c2);                                                                   \
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,      \
                      ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,       \
@@ -435,7 +470,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   else return S2S_ERR_DTYPE;
 #undef S2S_BN_BWD
   if (dbias_conv)
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part2, nb, C, dbias_conv,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part2, nb, C, dbias_conv,
                        accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;

@@ -34,10 +34,10 @@ BN_MOMENTUM = 0.1
 class ConvBN:
     """One Conv3x3 + BatchNorm2d pair of a DoubleConv, with its packed MFMA weight cache."""
 
-    def __init__(self, prefix: str, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d):
-        self.prefix = prefix            # e.g. "inc.double_conv"
+    def __init__(self, prefix: str, i_conv: str, i_bn: str, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d):
+        self.prefix = prefix            # e.g. "inc.double_conv"; parameter names are f"{prefix}.{i_conv}.weight" ...
+        self.idx = (i_conv, i_bn)       # ("0", "1") or ("3", "4"): positions inside the reference's nn.Sequential
         self.conv, self.bn = conv, bn
-        idx = {"0": ("0", "1"), "3": ("3", "4")}
         self._pack: Dict[torch.dtype, Tuple] = {}
         self._pack_key: Dict[torch.dtype, Tuple] = {}
 
@@ -169,10 +169,12 @@ def encoder_forward(blocks: Sequence[Tuple[ConvBN, ConvBN]], x_nchw: torch.Tenso
 
 
 def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeats: Sequence[Optional[torch.Tensor]],
-                     grads: Dict[str, torch.Tensor], accumulate: bool = False) -> None:
+                     grads: Dict[str, torch.Tensor], accumulate: bool = False, on_group_done=None) -> None:
     """dfeats[l]: gradient wrt level l's output activation (NHWC, or None); the max-pool path between the
-    levels is handled here."""
+    levels is handled here.  ``on_group_done(k)`` fires after the k-th level (deepest first) has all its
+    parameter gradients enqueued -- the data-parallel bucketer hangs its all-reduce launches on it."""
     gpool = None
+    nlev = len(blocks)
     for l in range(len(blocks) - 1, -1, -1):
         c1, c2 = blocks[l]
         lc1, lc2 = ctx.layers[l]
@@ -181,6 +183,8 @@ def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeat
             raise RuntimeError("stain2stain_amd: encoder level without any incoming gradient")
         ga1 = _conv_bn_relu_bwd(c2, lc2, g1, gpool, grads, accumulate, need_dx=True)
         gpool = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=(l > 0), stem=(l == 0))
+        if on_group_done is not None:
+            on_group_done(nlev - 1 - l)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -210,10 +214,14 @@ def decoder_forward(dec, bottleneck: torch.Tensor, skips: Sequence[torch.Tensor]
 
 
 def decoder_backward(dec, ctx: DecCtx, dv: torch.Tensor, grads: Dict[str, torch.Tensor], accumulate: bool = False,
-                     need_dt_emb: bool = False):
-    """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype."""
+                     need_dt_emb: bool = False, on_group_done=None):
+    """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype.
+    ``on_group_done(k)``: k = 0 after the head, 1.. after each Up block (last block first), then the time path."""
     g = ops.head_bwd(dv, ctx.lows[-1], dec.outc.weight.detach(), _g(grads, "outc.weight"),
                      _g(grads, "outc.bias") if dec.outc.bias is not None else None, accumulate)
+    if on_group_done is not None:
+        on_group_done(0)
+    nup = len(ctx.layers)
     dskips: List[torch.Tensor] = [None] * len(ctx.layers)
     for i in range(len(ctx.layers) - 1, -1, -1):
         c1, c2 = dec.up_blocks[i]
@@ -224,6 +232,8 @@ def decoder_backward(dec, ctx: DecCtx, dv: torch.Tensor, grads: Dict[str, torch.
         dskips[i] = dcat[..., :cs]
         low = ctx.lows[i]
         g = ops.upsample2x_bwd(dcat[..., cs:], low.shape[1], low.shape[2])
+        if on_group_done is not None:
+            on_group_done(nup - i)
     dbott = g
     # time path: tbias was broadcast-added to the bottleneck before the first up-sampling
     dtb = ops.pixel_sum(g)
@@ -235,4 +245,6 @@ def decoder_backward(dec, ctx: DecCtx, dv: torch.Tensor, grads: Dict[str, torch.
     dh1 = ops.silu_bwd(ctx.h1, da1)
     dt_emb = ops.linear_bwd(dh1, ctx.t_emb, l0.weight.detach(), _g(grads, "time_mlp.0.weight"),
                             _g(grads, "time_mlp.0.bias"), need_dt_emb, accumulate)
+    if on_group_done is not None:
+        on_group_done(nup + 1)
     return dbott, dskips, dt_emb

@@ -1,0 +1,122 @@
+"""Flow-matching step logic around the network, mirroring the reference's LightningModule surface.
+
+  reference                                                               here
+  ----------------------------------------------------------------------  ---------------------------
+  torchcfm.ConditionalFlowMatcher.sample_location_and_conditional_flow    ConditionalFlowMatcher
+    (third-party, call site src/models/conditional_flow_matching.py:66)
+  ConditionalFlowMatchingLitModule.model_step / training_step /           ConditionalFlowMatchingModule
+    configure_optimizers / generate (conditional_flow_matching.py:53-170)
+  NeuralODE(dopri5).trajectory in generate (:157-170, torchdyn, absent)   euler_generate (fixed step,
+                                                                          BASELINE.json config 4)
+
+``ConditionalFlowMatchingModule`` subclasses ``lightning.LightningModule`` when Lightning is
+importable and ``torch.nn.Module`` otherwise (this image has no Lightning), with the same method
+names, argument meaning and return values, so the reference's training loop can drive it.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+try:  # pragma: no cover - Lightning is not installed in the build image
+    from lightning import LightningModule as _Base
+except Exception:  # noqa: BLE001
+    class _Base(torch.nn.Module):
+        def log(self, *args, **kwargs) -> None:
+            pass
+
+
+class ConditionalFlowMatcher:
+    """Independent-coupling conditional flow matching: xt = t x1 + (1-t) x0 + sigma eps, ut = x1 - x0."""
+
+    def __init__(self, sigma: float = 0.0):
+        self.sigma = float(sigma)
+
+    def sample_location_and_conditional_flow(self, x0: torch.Tensor, x1: torch.Tensor,
+                                             t: Optional[torch.Tensor] = None, return_noise: bool = False):
+        if t is None:
+            t = torch.rand(x0.shape[0], device=x0.device, dtype=torch.float32)
+        eps = torch.randn_like(x0) if (self.sigma != 0.0 or return_noise) else None
+        xt, ut = ops.cfm_sample(x0.contiguous().float(), x1.contiguous().float(), t.contiguous().float(),
+                                self.sigma, eps)
+        return (t, xt, ut, eps) if return_noise else (t, xt, ut)
+
+
+class _MSE(torch.autograd.Function):
+    """mean((v-u)^2) with the fused loss/gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, v: torch.Tensor, u: torch.Tensor):
+        loss, dv = ops.mse_loss(v.detach().contiguous(), u.detach().contiguous(), want_grad=True)
+        ctx.save_for_backward(dv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dv,) = ctx.saved_tensors
+        return dv * gloss, None
+
+
+@torch.no_grad()
+def euler_generate(net: torch.nn.Module, source_img: torch.Tensor, num_steps: int = 50) -> torch.Tensor:
+    """x(0) = source, x <- x + v(t_k, x)/n at t_k = k/n, network in eval mode; returns x(1)."""
+    was_training = net.training
+    net.eval()
+    if source_img.dim() == 3:
+        source_img = source_img.unsqueeze(0)
+    x = source_img.detach().float().contiguous().clone()
+    dt = 1.0 / num_steps
+    for k in range(num_steps):
+        t = torch.full((x.shape[0],), k * dt, device=x.device, dtype=torch.float32)
+        v = net(t, x)
+        ops.axpy_(x, v.contiguous(), dt)
+    net.train(was_training)
+    return x
+
+
+class ConditionalFlowMatchingModule(_Base):
+    """Same surface as the reference's ConditionalFlowMatchingLitModule (logging hooks left out)."""
+
+    def __init__(self, net: torch.nn.Module, flow_matcher: Optional[ConditionalFlowMatcher] = None, solver=None,
+                 optimizer=None, scheduler=None, compile: bool = False, log_images: bool = False,
+                 n_images_log: int = 5):
+        super().__init__()
+        self.net = net
+        self.flow_matcher = flow_matcher or ConditionalFlowMatcher(0.0)
+        self.solver, self.optimizer, self.scheduler = solver, optimizer, scheduler
+        self.log_images, self.n_images_log = log_images, n_images_log
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        return self.net(t, x)
+
+    def model_step(self, batch: Tuple[torch.Tensor, ...]) -> torch.Tensor:
+        x0, x1 = batch[:2]
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(x0, x1)
+        vt = self.forward(t, xt)
+        return _MSE.apply(vt, ut)
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        loss = self.model_step(batch)
+        self.log("train/loss", loss, on_step=True, on_epoch=True, prog_bar=True, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx: int) -> None:
+        self.log("val/loss", self.model_step(batch), on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
+
+    def test_step(self, batch, batch_idx: int) -> None:
+        self.log("test/loss", self.model_step(batch), on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
+
+    def configure_optimizers(self) -> Dict[str, Any]:
+        optimizer = self.optimizer(params=self.parameters())
+        if self.scheduler is not None:
+            return {"optimizer": optimizer,
+                    "lr_scheduler": {"scheduler": self.scheduler(optimizer=optimizer), "monitor": "val/loss",
+                                     "interval": "epoch", "frequency": 1}}
+        return {"optimizer": optimizer}
+
+    @torch.no_grad()
+    def generate(self, source_img: torch.Tensor, num_steps: int = 100) -> torch.Tensor:
+        return euler_generate(self.net, source_img, num_steps)

@@ -65,8 +65,57 @@ def _L():
 
 
 # ------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
+# ------------------------------------------------------------------------------------------------
+_PROFILE: Optional[list] = None
+
+
+def profile_start() -> None:
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop() -> list:
+    """[(op name, algorithmic work, start event, end event)] recorded since profile_start()."""
+    global _PROFILE
+    out, _PROFILE = _PROFILE or [], None
+    return out
+
+
+def _timed(name: str, work_fn=None):
+    def deco(fn):
+        def wrapped(*args, **kwargs):
+            if _PROFILE is None:
+                return fn(*args, **kwargs)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kwargs)
+            e1.record()
+            _PROFILE.append((name, work_fn(*args, **kwargs) if work_fn else 0.0, e0, e1))
+            return out
+        wrapped.__name__ = fn.__name__
+        wrapped.__doc__ = fn.__doc__
+        return wrapped
+    return deco
+
+
+def _conv_flops(x0, x1, w_packed, bias, cout, **kw) -> float:
+    B, H, W, c0 = x0.shape
+    cin = c0 + (x1.shape[3] if x1 is not None else 0)
+    return 2.0 * B * H * W * cout * 9 * cin
+
+
+def _wgrad_flops(dy, x0, x1, grad_oihw, accumulate=False) -> float:
+    B, H, W, cout = dy.shape
+    cin = x0.shape[3] + (x1.shape[3] if x1 is not None else 0)
+    return 2.0 * B * H * W * cout * 9 * cin
+
+
+# ------------------------------------------------------------------------------------------------
 # convolutions
 # ------------------------------------------------------------------------------------------------
+@_timed("conv3x3_mfma", _conv_flops)
 def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
             cout: int, *, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
             shift: Optional[torch.Tensor] = None, relu: bool = False, out: Optional[torch.Tensor] = None):
@@ -89,7 +138,7 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     py, ldy = _nhwc(out)
     stat = None
     if want_stats:
-        nb = _L().s2s_conv3x3_stat_blocks(B, H, W, cout)
+        nb = _L().s2s_conv3x3_stat_blocks(dt, B, H, W, cout)
         stat = torch.empty((nb, 2, cout), dtype=torch.float32, device=x0.device)
     rc = _L().s2s_conv3x3_nhwc(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
                                _f32(scale), _f32(shift), int(relu), B, H, W, cout, _stream())
@@ -97,6 +146,7 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     return out, stat
 
 
+@_timed("conv3x3_wgrad_mfma", _wgrad_flops)
 def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], grad_oihw: torch.Tensor,
                   accumulate: bool = False) -> None:
     B, H, W, cout = dy.shape
@@ -119,6 +169,7 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
     _native.check(rc, "conv3x3_wgrad")
 
 
+@_timed("stem_fwd")
 def stem_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
              want_stats: bool = True):
     B, cin, H, W = x_nchw.shape
@@ -135,18 +186,20 @@ def stem_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     return y, stat
 
 
+@_timed("stem_wgrad")
 def stem_wgrad(dy: torch.Tensor, x_nchw: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor],
                accumulate: bool = False) -> None:
     B, H, W, cout = dy.shape
     cin = x_nchw.shape[1]
     pdy, lddy = _nhwc(dy)
     nb = _L().s2s_stem_wgrad_blocks(B, H, W)
-    part = torch.empty((nb, cout, cin * 9 + 1), dtype=torch.float32, device=dy.device)
+    part = torch.empty((2 * nb, cout, 32), dtype=torch.float32, device=dy.device)
     rc = _L().s2s_stem_conv3x3_wgrad(_dt(dy), pdy, lddy, _f32(x_nchw), _f32(part), _f32(dw), _f32(dbias),
                                      int(accumulate), B, H, W, cin, cout, _stream())
     _native.check(rc, "stem_conv3x3_wgrad")
 
 
+@_timed("head_fwd")
 def head_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     B, H, W, C = x.shape
     cout = w.shape[0]
@@ -158,6 +211,7 @@ def head_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> 
     return y
 
 
+@_timed("head_bwd")
 def head_bwd(dy_nchw: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor],
              accumulate: bool = False) -> torch.Tensor:
     B, H, W, C = x.shape
@@ -176,6 +230,7 @@ def head_bwd(dy_nchw: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.
 # ------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU (+ pool)
 # ------------------------------------------------------------------------------------------------
+@_timed("bn_finalize")
 def bn_finalize(stat: torch.Tensor, count: int, gamma, beta, running_mean, running_var, num_batches,
                 momentum: float = 0.1, eps: float = 1e-5):
     nblk, _, C = stat.shape
@@ -197,6 +252,7 @@ def bn_eval_prepare(gamma, beta, rmean, rvar, eps: float = 1e-5):
     return out
 
 
+@_timed("bn_relu_apply")
 def bn_relu_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out: Optional[torch.Tensor] = None,
                   pool: Optional[torch.Tensor] = None, want_pool: bool = False):
     B, H, W, C = x.shape
@@ -214,6 +270,7 @@ def bn_relu_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out
     return out, pool
 
 
+@_timed("maxpool2")
 def maxpool2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, C = x.shape
     px, ldx = _nhwc(x)
@@ -223,6 +280,7 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
     return pool
 
 
+@_timed("bn_relu_bwd")
 def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], y: torch.Tensor, x: torch.Tensor,
                 stats: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
                 dbias_conv: Optional[torch.Tensor], accumulate: bool = False) -> torch.Tensor:
@@ -245,6 +303,7 @@ def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], y: torch
 # ------------------------------------------------------------------------------------------------
 # resampling
 # ------------------------------------------------------------------------------------------------
+@_timed("upsample2x_fwd")
 def upsample2x_fwd(x: torch.Tensor, out: torch.Tensor, bias_nc: Optional[torch.Tensor] = None) -> None:
     B, Hin, Win, C = x.shape
     _, Hout, Wout, Co = out.shape
@@ -257,6 +316,7 @@ def upsample2x_fwd(x: torch.Tensor, out: torch.Tensor, bias_nc: Optional[torch.T
     _native.check(rc, "upsample2x_fwd")
 
 
+@_timed("upsample2x_bwd")
 def upsample2x_bwd(dy: torch.Tensor, hin: int, win: int) -> torch.Tensor:
     B, Hout, Wout, C = dy.shape
     pdy, lddy = _nhwc(dy)
@@ -316,6 +376,7 @@ def silu_bwd(h: torch.Tensor, da: torch.Tensor) -> torch.Tensor:
     return dh
 
 
+@_timed("cfm_sample")
 def cfm_sample(x0: torch.Tensor, x1: torch.Tensor, t: torch.Tensor, sigma: float = 0.0,
                eps: Optional[torch.Tensor] = None):
     xt = torch.empty_like(x0)
@@ -326,6 +387,7 @@ def cfm_sample(x0: torch.Tensor, x1: torch.Tensor, t: torch.Tensor, sigma: float
     return xt, ut
 
 
+@_timed("mse_loss")
 def mse_loss(v: torch.Tensor, u: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
     loss = torch.empty((), dtype=torch.float32, device=v.device)
     dv = torch.empty_like(v) if want_grad else None
@@ -346,6 +408,7 @@ def fill_(x: torch.Tensor, v: float) -> None:
 # ------------------------------------------------------------------------------------------------
 # optimiser / packing / layout
 # ------------------------------------------------------------------------------------------------
+@_timed("adam_step_")
 def adam_step_(p, g, m, v, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:
     _native.check(_L().s2s_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), int(step), float(lr), float(beta1),
@@ -353,6 +416,7 @@ def adam_step_(p, g, m, v, step: int, lr: float, beta1: float = 0.9, beta2: floa
                   "adam_step")
 
 
+@_timed("pack_conv3x3")
 def pack_conv3x3(w_oihw: torch.Tensor, dtype: torch.dtype, want_dgrad: bool = True, out=None):
     cout, cin = w_oihw.shape[:2]
     dev = w_oihw.device

@@ -1,0 +1,137 @@
+"""One whole optimisation step of the stain-translation model without autograd:
+
+    t, xt, ut  <- probability path sample        (conditional_flow_matching.py:66)
+    v          <- U-Net(t, xt)                    (:69)
+    loss       <- mean((v-ut)^2)                  (:72)
+    grads      <- backward through the U-Net      (Lightning automatic optimisation)
+    grads      <- bucketed RCCL all-reduce, overlapped with the rest of the backward (DDP, C1)
+    params     <- Adam                            (configure_optimizers, :112-131)
+
+This is the path ``bench.py`` times.  The LightningModule-compatible path (autograd Functions in
+components.py + any torch optimiser) produces the same numbers; this class removes the autograd /
+optimiser Python overhead, keeps all parameters, gradients and Adam moments in three flat fp32
+buffers and overlaps communication with compute.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from .components import FlowUNet
+from .ddp import GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
+
+
+def _param_groups(net: FlowUNet) -> List[List[Tuple[str, str, torch.nn.Parameter]]]:
+    """Parameters grouped in the order the backward pass finishes them.
+
+    Each entry is (owner, local_name, parameter) with owner in {"dec", "enc"}.
+    """
+    dec, enc = net.flow_decoder, net.encoder
+    dnamed = dict(dec.named_parameters())
+    enamed = dict(enc.named_parameters())
+    groups: List[List[Tuple[str, str, torch.nn.Parameter]]] = []
+    groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith("outc.")])
+    for i in range(len(dec.ups) - 1, -1, -1):
+        groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith(f"ups.{i}.")])
+    groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith("time_")])
+    for i in range(len(enc.downs) - 1, -1, -1):
+        groups.append([("enc", n, p) for n, p in enamed.items() if n.startswith(f"downs.{i}.")])
+    groups.append([("enc", n, p) for n, p in enamed.items() if n.startswith("inc.")])
+    seen = sum(len(g) for g in groups)
+    if seen != len(dnamed) + len(enamed):
+        raise RuntimeError("parameter grouping does not cover the network")
+    return groups
+
+
+class CFMTrainer:
+    def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
+                 bucket_mb: float = 32.0, process_group=None, sync_loss: bool = True):
+        dev = next(net.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("stain2stain_amd: CFMTrainer needs the network on a GPU (HIP-only implementation)")
+        self.net = net
+        self.lr, self.wd, self.betas, self.eps, self.sigma = lr, weight_decay, betas, eps, sigma
+        self.pg = process_group
+        self.sync_loss = sync_loss
+        self.step_count = 0
+        groups = _param_groups(net)
+        # 8-float alignment of every parameter keeps the flat views 32-byte aligned
+        sizes, offs, off = [], {}, 0
+        for g in groups:
+            start = off
+            for owner, name, p in g:
+                offs[(owner, name)] = off
+                off += (p.numel() + 7) // 8 * 8
+            sizes.append(off - start)
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads_enc: Dict[str, torch.Tensor] = {}
+        self.grads_dec: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            for g in groups:
+                for owner, name, p in g:
+                    o, n = offs[(owner, name)], p.numel()
+                    self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                    p.data = self.flat_p[o:o + n].view(p.shape)
+                    gv = self.flat_g[o:o + n].view(p.shape)
+                    p.grad = gv
+                    (self.grads_dec if owner == "dec" else self.grads_enc)[name] = gv
+        self.n_params = sum(p.numel() for g in groups for _, _, p in g)
+        self.n_dec_groups = 2 + len(net.flow_decoder.ups)
+        self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group)
+        broadcast_from_rank0([self.flat_p] + [b for b in net.buffers()], process_group)
+        self._blocks = list(net.encoder._blocks) + list(net.flow_decoder.up_blocks)
+        for pair in self._blocks:
+            for cb in pair:
+                cb.invalidate()
+
+    # ------------------------------------------------------------------------------------------
+    def forward_backward(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None):
+        """Gradients of the local batch into the flat buffer (+ async all-reduce).  Returns (loss, v)."""
+        net = self.net
+        enc, dec = net.encoder, net.flow_decoder
+        dt = enc.compute_dtype
+        B = x0.shape[0]
+        if t is None:
+            t = torch.rand(B, device=x0.device, dtype=torch.float32)
+        eps_noise = torch.randn_like(x0) if self.sigma != 0.0 else None
+        xt, ut = ops.cfm_sample(x0, x1, t, self.sigma, eps_noise)
+        ectx = engine.encoder_forward(enc._blocks, xt, dt, True)
+        temb = ops.time_embedding(t, net.time_embedding.dim)
+        feats = ectx.feats
+        dctx = engine.decoder_forward(dec, feats[-1], feats[:-1][::-1], temb, dt, True)
+        loss, dv = ops.mse_loss(dctx.v, ut, want_grad=True)
+        self.bucketer.start_step()
+        nd = self.n_dec_groups
+        dbott, dskips, _ = engine.decoder_backward(dec, dctx, dv, self.grads_dec,
+                                                   on_group_done=lambda k: self.bucketer.mark_ready(k))
+        L = len(feats) - 1
+        dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
+        engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc,
+                                on_group_done=lambda k: self.bucketer.mark_ready(nd + k))
+        return loss, dctx.v
+
+    def optimizer_step(self) -> None:
+        self.bucketer.wait_all()
+        self.step_count += 1
+        ops.adam_step_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas[0],
+                       self.betas[1], self.eps, self.wd, self.bucketer.grad_scale)
+        for pair in self._blocks:   # master weights changed behind torch's version counter
+            for cb in pair:
+                cb.invalidate()
+
+    def step(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One training step on this rank's shard of the global batch; returns the (rank-mean) loss."""
+        loss, _ = self.forward_backward(x0, x1, t)
+        work = all_reduce_mean_scalar(loss, self.pg) if self.sync_loss else None
+        self.optimizer_step()
+        if work is not None:
+            work.wait()
+            loss = loss / dist.get_world_size(self.pg)
+        return loss
