@@ -120,8 +120,12 @@ def test_eval_forward_and_euler_match_golden_fp32(golden_tiny):
 
 
 def test_bf16_mode_tracks_golden(golden_tiny):
-    """Throughput mode: bf16 activations/weights in the MFMAs.  Bounds are the measured ones with ~3x
-    headroom: velocity 3e-2, loss 1e-2, gradients 1e-1 of each tensor's own scale (max-norm)."""
+    """Throughput mode: bf16 activations/weights in the MFMAs, fp32 accumulation / statistics / master weights.
+    bf16 cannot meet 1e-3: the yardstick is the reference itself under torch.autocast(bfloat16) on the same
+    inputs (measured in the build container with the reference's modules: velocity error 1.25e-2, parameter
+    gradients up to 2.4e-1 max-norm -- BatchNorm's backward projects out most of the incoming gradient, which
+    amplifies 2^-9 rounding).  This path measured 1.1e-2 / 1.6e-1.  Bounds: velocity 3e-2, loss 1e-2,
+    gradients 3e-1 of each tensor's own max (tensors below 1% of the global gradient scale on that scale)."""
     from stain2stain_amd import CFMTrainer
     G = golden_tiny
     net = build_net(G, "bf16").train()
@@ -137,7 +141,7 @@ def test_bf16_mode_tracks_golden(golden_tiny):
     for k, r in ref.items():
         worst = max(worst, float((got[k].cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-2 * scale))
     print(f"bf16 tiny: v err {ev:.2e}, loss err {el:.2e}, worst grad err {worst:.2e}")
-    assert ev < 3e-2 and el < 1e-2 and worst < 1e-1
+    assert ev < 3e-2 and el < 1e-2 and worst < 3e-1
 
 
 def test_module_eval_backward_raises_and_cpu_raises(golden_tiny):
