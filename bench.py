@@ -43,7 +43,9 @@ def cpu_baseline(seconds_budget: float = 25.0):
     x0 = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
     x1 = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
     t = torch.rand(b, generator=g)
-    threads = torch.get_num_threads()
+    # a 1-GPU box owns a 16-core share of the host; more threads than that only oversubscribe it
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     O.train_steps(P, [(x0, x1, t)])          # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
