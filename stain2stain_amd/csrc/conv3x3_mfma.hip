@@ -28,6 +28,7 @@
 //   first, fp32 accumulation: fp32-grade products at 6/16 of the cost of the f32 MFMA.  This is the
 //   parity mode that is checked against the fp32 oracle.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 struct Conv3x3Args {
@@ -256,47 +257,101 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
     }
   }
 
-  // ---- epilogue: bias / folded affine / ReLU, store, per-channel partial statistics ----
-  float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN], LDS is free after the last barrier
+  // ---- epilogue: bias / folded affine / ReLU, per-channel partial statistics, coalesced store ----
+  // The accumulator tile goes through LDS (free after the last barrier) so that the global stores are
+  // whole pixel rows: 16 B per lane, BN*sizeof(T) contiguous bytes per pixel, instead of 2-byte scatters.
+  constexpr int RS = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);   // out-tile row stride (bytes), bank-staggered
+  // the staging tile must not be larger than the main-loop LDS (it would cost a resident workgroup): big
+  // tiles are flushed in EP passes, one group of WM/EP wave rows at a time
+  constexpr int LDS_MAIN = 2 * NIMG * (A_BYTES + B_BYTES);
+  constexpr int EP = (BM * RS + WM * 2 * BN * 4 <= LDS_MAIN) ? 1 : ((BM / 2) * RS + WM * 2 * BN * 4 <= LDS_MAIN ? 2 : 4);
+  static_assert(WM % EP == 0 || EP == 1, "epilogue passes split the wave rows");
+  constexpr int PM = BM / EP;                                         // pixels per pass
+  char* const otile = smem;                                           // [PM][RS]
+  float* const red = reinterpret_cast<float*>(smem + PM * RS);       // [WM][2][BN]
   const bool want_stats = a.stat_part != nullptr;
+  float s1[NI], s2[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int nl = wn * WTN + ni * 32 + r;
-    const int n = n0 + nl;
-    const bool nok = n < a.Cout;
-    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
-    const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
-    const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+  for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+  for (int ep = 0; ep < EP; ++ep) {
+    if (ep > 0) __syncthreads();
+    if (wm / (WM / EP) == ep || EP == 1) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-        const int m = wm * WTM + mi * 32 + row;
-        const int py = m / TW, px = m - py * TW;
-        const int gy = y0 + py, gx = x0p + px;
-        float v = acc[mi][ni][j] + bias;
-        if (a.ep_scale) v = v * esc + esh;
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (nok && gy < a.H && gx < a.W) {
-          yout[(((long)img * a.H + gy) * a.W + gx) * a.ldy + n] = from_f32<T>(v);
-          s1 += v;
-          s2 += v * v;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nl = wn * WTN + ni * 32 + r;
+        const int n = n0 + nl;
+        const bool nok = n < a.Cout;
+        const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+        const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
+        const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            const int m = wm * WTM + mi * 32 + row;
+            const int py = m / TW, px = m - py * TW;
+            float t = acc[mi][ni][j] + bias;
+            if (a.ep_scale) t = t * esc + esh;
+            if (a.relu) t = fmaxf(t, 0.f);
+            v[j] = t;
+            if (nok && y0 + py < a.H && x0p + px < a.W) { s1[ni] += t; s2[ni] += t * t; }
+          }
+          const int mrow0 = wm * WTM + mi * 32 + 4 * h - ep * PM;
+          if constexpr (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              *reinterpret_cast<float*>(otile + (mrow0 + (j & 3) + 8 * (j >> 2)) * RS + nl * 4) = v[j];
+          } else {
+            // lanes (2k, 2k+1) hold channels (n, n+1) of the same rows: swap so each lane owns a channel
+            // PAIR of one row and writes one dword -- even lane row j, odd lane row j+1
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+              const float got = __shfl_xor(odd ? v[j] : v[j + 1], 1, 64);
+              bf16x2 pk;
+              pk[0] = (bf16_t)(odd ? got : v[j]);
+              pk[1] = (bf16_t)(odd ? v[j + 1] : got);
+              const int mr = mrow0 + ((j + (odd ? 1 : 0)) & 3) + 8 * (j >> 2);
+              *reinterpret_cast<bf16x2*>(otile + mr * RS + (nl & ~1) * 2) = pk;
+            }
+          }
         }
       }
     }
-    if (want_stats) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + nl] = s1;
-        red[(wm * 2 + 1) * BN + nl] = s2;
+    __syncthreads();
+    constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-B chunk
+    constexpr int CPR = BN / EPC;                     // chunks per pixel row
+    constexpr int O_IT = (PM * CPR + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < O_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int ml = idx / CPR, c = idx - ml * CPR;
+      const int m = ml + ep * PM;
+      const int py = m / TW, px = m - py * TW;
+      const int gy = y0 + py, gx = x0p + px, n = n0 + c * EPC;
+      if (idx < PM * CPR && gy < a.H && gx < a.W && n < a.Cout) {
+        const f32x4 val = *reinterpret_cast<const f32x4*>(otile + ml * RS + c * 16);
+        *reinterpret_cast<f32x4*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
       }
     }
   }
   if (want_stats) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wn * WTN + ni * 32 + r;
+      const float t1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
+      const float t2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + nl] = t1;
+        red[(wm * 2 + 1) * BN + nl] = t2;
+      }
+    }
     __syncthreads();
+  }
+  if (want_stats) {
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, nl = i - which * BN;
       if (n0 + nl < a.Cout) {
@@ -311,8 +366,14 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 
 template <typename T, int TH, int TW, int BN, int WM, int WN>
 int launch_cfg(Conv3x3Args& a, hipStream_t s) {
-  constexpr int NIMG = std::is_same<T, float>::value ? 3 : 1;
-  constexpr int lds = 2 * NIMG * ((TH + 2) * (TW + 2) + BN) * ROWB;
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 3 : 1;
+  constexpr int lds_main = 2 * NIMG * ((TH + 2) * (TW + 2) + BN) * ROWB;
+  constexpr int RS_ = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);
+  constexpr int red_ = WM * 2 * BN * 4;
+  constexpr int EP_ = (TH * TW * RS_ + red_ <= lds_main) ? 1 : ((TH * TW / 2) * RS_ + red_ <= lds_main ? 2 : 4);
+  constexpr int lds_epi = (TH * TW / EP_) * RS_ + red_;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
@@ -329,31 +390,54 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
-// tile geometry of one launch; s2s_conv3x3_stat_blocks must agree with it
-template <typename T> struct Geo;
-template <> struct Geo<bf16_t> { static constexpr int TH = 8, TW = 32, NTH = 16, NTW = 16; };
-template <> struct Geo<float> { static constexpr int TH = 4, TW = 32, NTH = 8, NTW = 16; };
+// ---- tile configuration table -----------------------------------------------------------------------
+// The largest tile whose grid still gives every CU about two workgroups wins; small feature maps
+// (16x16 ... 32x32 at batch 16) fall through to smaller tiles so that the 256 CUs stay busy.
+struct TileCfg { int th, tw, bn; };
+constexpr TileCfg kBf16Cfg[8] = {{8, 32, 128}, {8, 32, 64}, {4, 32, 128}, {4, 32, 64},
+                                 {16, 16, 128}, {16, 16, 64}, {8, 16, 128}, {8, 16, 64}};
+constexpr TileCfg kF32Cfg[2] = {{4, 32, 64}, {8, 16, 64}};
+constexpr int kMinBlocks = 448;
 
-template <typename T>
-int dispatch(Conv3x3Args& a, hipStream_t s);
-
-template <>
-int dispatch<float>(Conv3x3Args& a, hipStream_t s) {
-  // three bf16 images per operand: smaller tiles so the double-buffered LDS still fits
-  if (a.W <= 16) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
-  return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
+inline long cfg_blocks(const TileCfg& c, int B, int H, int W, int Cout) {
+  return (long)B * cdiv(H, c.th) * cdiv(W, c.tw) * cdiv(Cout, c.bn);
 }
 
-template <>
-int dispatch<bf16_t>(Conv3x3Args& a, hipStream_t s) {
-  using T = bf16_t;
-  const bool narrow = a.W <= 16;
-  if (a.Cout <= 64) {
-    if (narrow) return launch_cfg<T, 16, 16, 64, 4, 1>(a, s);
-    return launch_cfg<T, 8, 32, 64, 4, 1>(a, s);
+int select_cfg(int dtype, int B, int H, int W, int Cout) {
+  if (dtype == S2S_F32) return W <= 16 ? 1 : 0;
+  const char* force = getenv("S2S_CONV_CFG");
+  if (force && force[0] >= '0' && force[0] <= '7') return force[0] - '0';
+  const int first = W <= 16 ? 4 : 0;
+  int best = -1;
+  long best_blocks = -1;
+  for (int i = first; i < first + 4; ++i) {
+    const TileCfg& c = kBf16Cfg[i];
+    if (c.bn == 128 && Cout <= 64) continue;
+    const long nb = cfg_blocks(c, B, H, W, Cout);
+    if (nb >= kMinBlocks) return i;
+    if (nb > best_blocks) { best_blocks = nb; best = i; }
   }
-  if (narrow) return launch_cfg<T, 16, 16, 128, 2, 2>(a, s);
-  return launch_cfg<T, 8, 32, 128, 2, 2>(a, s);
+  return best;
+}
+
+int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
+  const int id = select_cfg(dtype, a.B, a.H, a.W, a.Cout);
+  if (dtype == S2S_F32) {
+    // three bf16 images per operand: small tiles so the double-buffered LDS still fits
+    if (id == 1) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
+    return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
+  }
+  switch (id) {
+    case 0: return launch_cfg<bf16_t, 8, 32, 128, 2, 2>(a, s);
+    case 1: return launch_cfg<bf16_t, 8, 32, 64, 4, 1>(a, s);
+    case 2: return launch_cfg<bf16_t, 4, 32, 128, 2, 2>(a, s);
+    case 3: return launch_cfg<bf16_t, 4, 32, 64, 2, 2>(a, s);
+    case 4: return launch_cfg<bf16_t, 16, 16, 128, 2, 2>(a, s);
+    case 5: return launch_cfg<bf16_t, 16, 16, 64, 4, 1>(a, s);
+    case 6: return launch_cfg<bf16_t, 8, 16, 128, 2, 2>(a, s);
+    case 7: return launch_cfg<bf16_t, 8, 16, 64, 2, 2>(a, s);
+  }
+  return S2S_ERR_SHAPE;
 }
 
 }  // namespace
@@ -361,17 +445,11 @@ int dispatch<bf16_t>(Conv3x3Args& a, hipStream_t s) {
 // Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
 // (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.
 extern "C" int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout) {
-  (void)Cout;
-  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
-  if (dtype == S2S_BF16) {
-    if (W <= 16) return B * cdiv(H, Geo<bf16_t>::NTH) * cdiv(W, Geo<bf16_t>::NTW);
-    return B * cdiv(H, Geo<bf16_t>::TH) * cdiv(W, Geo<bf16_t>::TW);
-  }
-  if (dtype == S2S_F32) {
-    if (W <= 16) return B * cdiv(H, Geo<float>::NTH) * cdiv(W, Geo<float>::NTW);
-    return B * cdiv(H, Geo<float>::TH) * cdiv(W, Geo<float>::TW);
-  }
-  return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  const int id = select_cfg(dtype, B, H, W, Cout);
+  const TileCfg& c = dtype == S2S_F32 ? kF32Cfg[id] : kBf16Cfg[id];
+  return B * cdiv(H, c.th) * cdiv(W, c.tw);
 }
 
 extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
@@ -391,7 +469,6 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == S2S_BF16) return dispatch<bf16_t>(a, s);
-  if (dtype == S2S_F32) return dispatch<float>(a, s);
-  return S2S_ERR_DTYPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  return dispatch(dtype, a, s);
 }

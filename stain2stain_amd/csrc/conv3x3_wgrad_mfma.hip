@@ -219,20 +219,33 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
+// grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci]; one thread per (co, ci, tap) with ci fastest across lanes
+// for the reads; the 9 taps of one (co,ci) are gathered through LDS so the OIHW store is contiguous.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
                                     int Cin, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (co, ci)
+  __shared__ float tile[9][257];
   const long n = (long)Cout * Cin;
-  if (i >= n) return;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (co, ci)
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  for (int z = 0; z < S; ++z)
+  if (i < n) {
+    for (int z = 0; z < S; ++z)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] += part[((long)z * 9 + t) * n + i];
-  float* g = grad + i * 9;  // OIHW: [co][ci][kh][kw]
+      for (int t = 0; t < 9; ++t) s[t] += part[((long)z * 9 + t) * n + i];
+  }
 #pragma unroll
-  for (int t = 0; t < 9; ++t) g[t] = accumulate ? g[t] + s[t] : s[t];
+  for (int t = 0; t < 9; ++t) tile[t][threadIdx.x] = s[t];
+  __syncthreads();
+  // 256 (co,ci) pairs x 9 taps = 2304 contiguous floats of the OIHW gradient
+  const long base = (long)blockIdx.x * 256 * 9;
+  for (int k = threadIdx.x; k < 2304; k += 256) {
+    const long o = base + k;
+    if (o < n * 9) {
+      const float v = tile[k % 9][k / 9];
+      grad[o] = accumulate ? grad[o] + v : v;
+    }
+  }
 }
 
 template <typename T, int TH, int TW>
@@ -268,7 +281,7 @@ extern "C" int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) 
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = wgrad_ntiles(B, H, W);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
-  int s = cdiv(768, mn);
+  int s = cdiv(320, mn);   // ~320-512 workgroups: enough to fill 256 CUs twice, few enough partial slabs
   if (s > nt) s = nt;
   if (s < 1) s = 1;
   return s;

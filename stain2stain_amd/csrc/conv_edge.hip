@@ -218,17 +218,25 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
+// one workgroup per output channel: 32 k-columns x 8 slab groups
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
                                          int accumulate) {
+  __shared__ double red[8][33];
   const int K = Cin * 9;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cout * 32) return;
-  const int co = i >> 5, k = i & 31;
-  if (k > K || (k == K && !db)) return;
+  const int co = blockIdx.x, k = threadIdx.x & 31, sg = threadIdx.x >> 5;
   double s = 0.0;
-  for (int b = 0; b < nslab; ++b) s += (double)part[(long)b * Cout * 32 + i];
-  float* dst = (k < K) ? dw + co * K + k : db + co;
-  *dst = accumulate ? *dst + (float)s : (float)s;
+  for (int b = sg; b < nslab; b += 8) s += (double)part[((long)b * Cout + co) * 32 + k];
+  red[sg][k] = s;
+  __syncthreads();
+  if (sg == 0) {
+    for (int j = 1; j < 8; ++j) s += red[j][k];
+    if (k < K) {
+      float* dst = dw + co * K + k;
+      *dst = accumulate ? *dst + (float)s : (float)s;
+    } else if (k == K && db) {
+      db[co] = accumulate ? db[co] + (float)s : (float)s;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,17 +346,24 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
-__global__ void head_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int C, float* dw, float* db,
+// part[nblk][nout] -> dw/db; 32 outputs x 8 block groups per workgroup
+__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int C, float* dw, float* db,
                                          int accumulate) {
+  __shared__ double red[8][33];
   const int nout = Cout * (C + 1);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nout) return;
-  const int o = i / (C + 1), c = i - o * (C + 1);
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), sg = threadIdx.x >> 5;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * nout + i];
-  if (c == C && !db) return;
-  float* dst = (c < C) ? dw + o * C + c : db + o;
-  *dst = accumulate ? *dst + (float)s : (float)s;
+  if (i < nout)
+    for (int b = sg; b < nblk; b += 8) s += (double)part[(long)b * nout + i];
+  red[sg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (sg == 0 && i < nout) {
+    for (int j = 1; j < 8; ++j) s += red[j][threadIdx.x & 31];
+    const int o = i / (C + 1), c = i - o * (C + 1);
+    if (c == C && !db) return;
+    float* dst = (c < C) ? dw + o * C + c : db + o;
+    *dst = accumulate ? *dst + (float)s : (float)s;
+  }
 }
 
 }  // namespace
@@ -381,7 +396,7 @@ extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float*
 extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
   const int nt = B * cdiv(H, 16) * cdiv(W, 16);
-  return nt < 512 ? nt : 512;
+  return nt < 256 ? nt : 256;
 }
 
 // part: float[2*blocks][Cout][32]
@@ -410,8 +425,8 @@ extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, lddy, x_nchw, part, B, H,
                        W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else return S2S_ERR_DTYPE;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(Cout * 32, 256)), dim3(256), 0, s, part, 2 * nb, Cout, Cin,
-                     dw_oihw, dbias, accumulate);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout), dim3(256), 0, s, part, 2 * nb, Cout, Cin, dw_oihw, dbias,
+                     accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -439,7 +454,7 @@ extern "C" int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const flo
 extern "C" int s2s_head_wgrad_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
   const long nb = ((long)B * H * W + 63) / 64;
-  return (int)(nb < 1024 ? nb : 1024);
+  return (int)(nb < 512 ? nb : 512);
 }
 
 // part: float[blocks][Cout][C+1]
@@ -465,7 +480,7 @@ extern "C" int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void*
   else if (dtype == S2S_F32) { S2S_HEAD_BWD(float) }
   else return S2S_ERR_DTYPE;
 #undef S2S_HEAD_BWD
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 256)), dim3(256), 0, s, part, nb, Cout, C,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
                      dw, dbias, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;

@@ -36,15 +36,18 @@ __global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __re
   if (lane == 0) y[o] = s + (bias ? bias[n] : 0.f);
 }
 
-// dx[b][k] = sum_n dy[b][n] W[n][k]
-__global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+// dx[b][k] = sum_n dy[b][n] W[n][k]; workgroup = (b, 64 k-columns), 4 waves split n, lanes walk k (coalesced)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                     float* __restrict__ dx, int B, int K, int N) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * K) return;
-  const int b = i / K, k = i - b * K;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y, k = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s = fmaf(dy[(long)b * N + n], w[(long)n * K + k], s);
-  dx[i] = s;
+  if (k < K)
+    for (int n = wv; n < N; n += 4) s = fmaf(dy[(long)b * N + n], w[(long)n * K + k], s);
+  red[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && k < K) dx[(long)b * K + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // dW[n][k] (+)= sum_b dy[b][n] x[b][k];  db[n] (+)= sum_b dy[b][n]
@@ -111,12 +114,17 @@ __global__ void mse_partial_kernel(const f32x4* __restrict__ v, const f32x4* __r
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-__global__ void mse_finalize_kernel(const double* part, int n, double inv_count, float* loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += part[i];
-    *loss = (float)(s * inv_count);
+__global__ __launch_bounds__(256) void mse_finalize_kernel(const double* part, int n, double inv_count, float* loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
 }
 
 __global__ void axpy_kernel(f32x4* __restrict__ x, const f32x4* __restrict__ y, float a, long total4) {
@@ -161,7 +169,7 @@ extern "C" int s2s_linear_bwd(const float* dy, const float* x, const float* w, f
   if (!dy || !x || !w || !dw) return S2S_ERR_NULL;
   if (B <= 0 || K <= 0 || N <= 0) return S2S_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(B * K, 256)), dim3(256), 0, s, dy, w, dx, B, K, N);
+  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(K, 64), B), dim3(256), 0, s, dy, w, dx, B, K, N);
   hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(N * (K + 1), 256)), dim3(256), 0, s, dy, x, dw, db, B, K, N,
                      accumulate);
   S2S_LAUNCH_CHECK();
@@ -208,7 +216,7 @@ extern "C" int s2s_mse_loss(const float* v, const float* u, float* dv, float gra
   if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
   hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, (const f32x4*)v, (const f32x4*)u, (f32x4*)dv,
                      (float)(2.0 * (double)grad_scale / (double)count), count / 4, work);
-  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, s, work, nb, 1.0 / (double)count, loss);
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, s, work, nb, 1.0 / (double)count, loss);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
