@@ -30,6 +30,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 struct Conv3x3Args {
   const void* x0;
@@ -46,6 +47,16 @@ struct Conv3x3Args {
 };
 
 namespace {
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time loop: the body receives the index as an integral_constant (usable as a template argument)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
 
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
                   ? (img * a.H + gy) * a.W + gx : -1;
   }
   Piece<T> hreg[A_IT];
-  Piece<T> wreg[B_IT];
+  Piece<T> wreg[3][B_IT];   // three rotating sets (slab index mod 3 == tap mod 3): two taps of load latency
 
   auto load_halo = [&](int c) {
 #pragma unroll
@@ -153,23 +164,25 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
       if (idx < A_PIECES) hreg[i].to_lds(hi, A_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
     }
   };
-  auto load_w = [&](int it) {
+  auto load_w = [&](int it, auto setc) {
+    constexpr int set = decltype(setc)::value;
     const int c = it / 9, tap = it - c * 9;
     const T* base = wp + ((long)(tap * a.nchunk + c) * a.Cout) * 32;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 2, pc = idx & 3;
-      wreg[i].zero();
-      if (idx < B_PIECES && n0 + row < a.Cout) wreg[i].load(base + (long)(n0 + row) * 32 + pc * 8);
+      wreg[set][i].zero();
+      if (idx < B_PIECES && n0 + row < a.Cout) wreg[set][i].load(base + (long)(n0 + row) * 32 + pc * 8);
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf, auto setc) {
+    constexpr int set = decltype(setc)::value;
     char* hi = ldsB + buf * NIMG * B_BYTES;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int idx = tid + i * 256;
-      if (idx < B_PIECES) wreg[i].to_lds(hi, B_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
+      if (idx < B_PIECES) wreg[set][i].to_lds(hi, B_BYTES, (idx >> 2) * ROWB + (idx & 3) * 16);
     }
   };
 
@@ -196,18 +209,22 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   const int nit = a.nchunk * 9;
 
   // ---- prologue ----
-  load_w(0);
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  load_w(0, I0{});
   load_halo(0);
-  store_w(0);
+  store_w(0, I0{});
   store_halo(0);
-  if (nit > 1) load_w(1);
+  if (nit > 1) load_w(1, I1{});
+  if (nit > 2) load_w(2, I2{});
   __syncthreads();
 
   for (int c = 0; c < a.nchunk; ++c) {
     if (c + 1 < a.nchunk) load_halo(c + 1);
     const char* Ahi = ldsA + (c & 1) * NIMG * A_BYTES;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    static_for<9>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
       const int it = c * 9 + tap;
       const char* Bhi = ldsB + (it & 1) * NIMG * B_BYTES;
       const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
@@ -250,11 +267,13 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
       }
       // slot (it+1)&1 was last read by tap it-1, which every wave left at the previous barrier
-      if (it + 1 < nit) store_w((it + 1) & 1);
-      if (it + 2 < nit) load_w(it + 2);
+      // slab it+1 sits in register set (tap+1)%3 (loaded two taps ago); slab it+3 goes into the set that
+      // held slab it (tap%3), whose LDS copy was written one tap ago
+      if (it + 1 < nit) store_w((it + 1) & 1, std::integral_constant<int, (tap + 1) % 3>{});
+      if (it + 3 < nit) load_w(it + 3, std::integral_constant<int, tap % 3>{});
       if (tap == 8 && c + 1 < a.nchunk) store_halo((c + 1) & 1);
       __syncthreads();
-    }
+    });
   }
 
   // ---- epilogue: bias / folded affine / ReLU, per-channel partial statistics, coalesced store ----

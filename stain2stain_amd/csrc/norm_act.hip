@@ -15,6 +15,7 @@
 // channel slice of a wider buffer (the decoder's concat buffer) can be read or written in place.
 // Every thread moves 16-B (bf16) / 32-B (fp32) pieces: 8 consecutive channels of one pixel.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -222,9 +223,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
   const int PCB = pcb_of(C), WL = 256 / PCB;
   const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
   const int c8 = (blockIdx.x * PCB + pc) * 8;
-  float s1[8], s2[8];
+  // parity mode accumulates in fp64 (as ATen's CPU batch_norm backward does): sum(dz) cancels heavily once
+  // training is under way, and its error is multiplied by the all-positive activations in the next wgrad
+  using Acc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  Acc s1[8], s2[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
   if (c8 < C) {
     for (long w = (long)blockIdx.y * WL + wl; w < nwin; w += (long)gridDim.y * WL) {
       long t = w;
@@ -234,22 +238,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
       WindowGrad<T> wg;
       wg.load(g1, ldg1, gp, ldgp, y, ldy, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int k = 0; k < 8; ++k) {
+        float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { s1[k] += wg.dz[q][k]; s2[k] += wg.dz[q][k] * wg.xh[q][k]; }
+        for (int q = 0; q < 4; ++q) { a += wg.dz[q][k]; b += wg.dz[q][k] * wg.xh[q][k]; }
+        s1[k] += (Acc)a;
+        s2[k] += (Acc)b;
+      }
     }
   }
-  __shared__ float red[2][2304];
+  __shared__ Acc red[2][2304];
   const int rowlen = PCB * 8 + 1;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { red[0][wl * rowlen + pc * 8 + k] = s1[k]; red[1][wl * rowlen + pc * 8 + k] = s2[k]; }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * PCB * 8; i += 256) {
     const int which = i / (PCB * 8), cl = i - which * (PCB * 8);
-    float s = 0.f;
+    Acc s = 0;
     for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
     const int c = blockIdx.x * PCB * 8 + cl;
-    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = s;
+    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = (float)s;
   }
 }
 
@@ -314,6 +322,95 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int
         }
         store8(dx + pix * lddx + c8, o);
       }
+    }
+  }
+  if (dxsum_part) {
+    __shared__ float red[2304];
+    const int rowlen = PCB * 8 + 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wl * rowlen + pc * 8 + k] = s[k];
+    __syncthreads();
+    for (int cl = threadIdx.x; cl < PCB * 8; cl += 256) {
+      float t = 0.f;
+      for (int r = 0; r < WL; ++r) t += red[r * rowlen + cl];
+      const int c = blockIdx.x * PCB * 8 + cl;
+      if (c < C) dxsum_part[(long)blockIdx.y * C + c] = t;
+    }
+  }
+}
+
+// ---- flat variants (no max-pool gradient): one pixel x 8 channels per thread-iteration, pure streaming ----
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* __restrict__ g1, int ldg1, const T* __restrict__ y, int ldy,
+                                               const T* __restrict__ x, int ldx, const float* mean, const float* invstd,
+                                               float* part, long npix, int C) {
+  const int PCB = pcb_of(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int c8 = (blockIdx.x * PCB + pc) * 8;
+  using Acc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
+  Acc s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
+  if (c8 < C) {
+    float mu[8], is[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k]; }
+    for (long p = (long)blockIdx.y * WL + wl; p < npix; p += (long)gridDim.y * WL) {
+      const f32x8 g = load8(g1 + p * ldg1 + c8);
+      const f32x8 a = load8(y + p * ldy + c8);
+      const f32x8 b = load8(x + p * ldx + c8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dz = a.v[k] > 0.f ? g.v[k] : 0.f;
+        s1[k] += (Acc)dz;
+        s2[k] += (Acc)(dz * ((b.v[k] - mu[k]) * is[k]));
+      }
+    }
+  }
+  __shared__ Acc red[2][2304];
+  const int rowlen = PCB * 8 + 1;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][wl * rowlen + pc * 8 + k] = s1[k]; red[1][wl * rowlen + pc * 8 + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * PCB * 8; i += 256) {
+    const int which = i / (PCB * 8), cl = i - which * (PCB * 8);
+    Acc s = 0;
+    for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
+    const int c = blockIdx.x * PCB * 8 + cl;
+    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = (float)s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __restrict__ g1, int ldg1, const T* __restrict__ y, int ldy,
+                                              const T* __restrict__ x, int ldx, const float* mean, const float* invstd,
+                                              const float* gamma, const float* c1, const float* c2, T* __restrict__ dx,
+                                              int lddx, float* dxsum_part, long npix, int C) {
+  const int PCB = pcb_of(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int c8 = (blockIdx.x * PCB + pc) * 8;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  if (c8 < C) {
+    float ga[8], k1[8], k2[8], mu[8], is[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k];
+      ga[k] = gamma[c8 + k] * is[k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k];
+    }
+    for (long p = (long)blockIdx.y * WL + wl; p < npix; p += (long)gridDim.y * WL) {
+      const f32x8 g = load8(g1 + p * ldg1 + c8);
+      const f32x8 a = load8(y + p * ldy + c8);
+      const f32x8 b = load8(x + p * ldx + c8);
+      f32x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dz = a.v[k] > 0.f ? g.v[k] : 0.f;
+        o.v[k] = ga[k] * (dz - k1[k] - ((b.v[k] - mu[k]) * is[k]) * k2[k]);
+        s[k] += o.v[k];
+      }
+      store8(dx + p * lddx + c8, o);
     }
   }
   if (dxsum_part) {
@@ -458,13 +555,24 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
 #define S2S_BN_BWD(TT)                                                                                             \
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,     \
-                     ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                  \
+  if (gp) {                                                                                                        \
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,   \
+                       ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                \
+  } else {                                                                                                         \
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,             \
+                       (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
+  }                                                                                                                \
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, nb, C, count, dgamma,      \
                      dbeta, accumulate, c1, c2);                                                                   \
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,      \
-                     ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,       \
-                     dbias_conv ? part2 : nullptr, B, H, W, C);
+  if (gp) {                                                                                                        \
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
+                       ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
+                       dbias_conv ? part2 : nullptr, B, H, W, C);                                                  \
+  } else {                                                                                                         \
+    hipLaunchKernelGGL(bn_relu_bwd_apply_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,              \
+                       (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,           \
+                       dbias_conv ? part2 : nullptr, (long)B * H * W, C);                                          \
+  }
   if (dtype == S2S_BF16) { S2S_BN_BWD(bf16_t) }
   else if (dtype == S2S_F32) { S2S_BN_BWD(float) }
   else return S2S_ERR_DTYPE;
