@@ -98,6 +98,122 @@ template <> struct Piece<float> {
   }
 };
 
+// ---- epilogue shared by both main loops ---------------------------------------------------------------
+// bias / folded affine / ReLU, per-channel partial statistics, coalesced store.
+template <typename T, int TH, int TW, int BN, int WM, int WN, int LDS_MAIN>
+__device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc)[(TH * TW / WM) / 32][(BN / WN) / 32],
+                                              char* smem, int img, int y0, int x0p, int n0) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  T* __restrict__ yout = static_cast<T*>(a.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  // The accumulator tile goes through LDS (free after the last barrier) so that the global stores are
+  // whole pixel rows: 16 B per lane, BN*sizeof(T) contiguous bytes per pixel, instead of 2-byte scatters.
+  constexpr int RS = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);   // out-tile row stride (bytes), bank-staggered
+  // the staging tile must not be larger than the main-loop LDS (it would cost a resident workgroup): big
+  // tiles are flushed in EP passes, one group of WM/EP wave rows at a time
+  constexpr int EP = (BM * RS + WM * 2 * BN * 4 <= LDS_MAIN) ? 1 : ((BM / 2) * RS + WM * 2 * BN * 4 <= LDS_MAIN ? 2 : 4);
+  static_assert(WM % EP == 0 || EP == 1, "epilogue passes split the wave rows");
+  constexpr int PM = BM / EP;                                         // pixels per pass
+  char* const otile = smem;                                           // [PM][RS]
+  float* const red = reinterpret_cast<float*>(smem + PM * RS);       // [WM][2][BN]
+  const bool want_stats = a.stat_part != nullptr;
+  float s1[NI], s2[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+#pragma unroll
+  for (int ep = 0; ep < EP; ++ep) {
+    if (ep > 0) __syncthreads();
+    if (wm / (WM / EP) == ep || EP == 1) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nl = wn * WTN + ni * 32 + r;
+        const int n = n0 + nl;
+        const bool nok = n < a.Cout;
+        const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+        const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
+        const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            const int m = wm * WTM + mi * 32 + row;
+            const int py = m / TW, px = m - py * TW;
+            float t = acc[mi][ni][j] + bias;
+            if (a.ep_scale) t = t * esc + esh;
+            if (a.relu) t = fmaxf(t, 0.f);
+            v[j] = t;
+            if (nok && y0 + py < a.H && x0p + px < a.W) { s1[ni] += t; s2[ni] += t * t; }
+          }
+          const int mrow0 = wm * WTM + mi * 32 + 4 * h - ep * PM;
+          if constexpr (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              *reinterpret_cast<float*>(otile + (mrow0 + (j & 3) + 8 * (j >> 2)) * RS + nl * 4) = v[j];
+          } else {
+            // lanes (2k, 2k+1) hold channels (n, n+1) of the same rows: swap so each lane owns a channel
+            // PAIR of one row and writes one dword -- even lane row j, odd lane row j+1
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+              const float got = __shfl_xor(odd ? v[j] : v[j + 1], 1, 64);
+              bf16x2 pk;
+              pk[0] = (bf16_t)(odd ? got : v[j]);
+              pk[1] = (bf16_t)(odd ? v[j + 1] : got);
+              const int mr = mrow0 + ((j + (odd ? 1 : 0)) & 3) + 8 * (j >> 2);
+              *reinterpret_cast<bf16x2*>(otile + mr * RS + (nl & ~1) * 2) = pk;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-B chunk
+    constexpr int CPR = BN / EPC;                     // chunks per pixel row
+    constexpr int O_IT = (PM * CPR + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < O_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int ml = idx / CPR, c = idx - ml * CPR;
+      const int m = ml + ep * PM;
+      const int py = m / TW, px = m - py * TW;
+      const int gy = y0 + py, gx = x0p + px, n = n0 + c * EPC;
+      if (idx < PM * CPR && gy < a.H && gx < a.W && n < a.Cout) {
+        const f32x4 val = *reinterpret_cast<const f32x4*>(otile + ml * RS + c * 16);
+        *reinterpret_cast<f32x4*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
+      }
+    }
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wn * WTN + ni * 32 + r;
+      const float t1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
+      const float t2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + nl] = t1;
+        red[(wm * 2 + 1) * BN + nl] = t2;
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) {
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, nl = i - which * BN;
+      if (n0 + nl < a.Cout) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) s += red[(k * 2 + which) * BN + nl];
+        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = s;
+      }
+    }
+  }
+}
+
 template <typename T, int TH, int TW, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr bool SPLIT = std::is_same<T, float>::value;
@@ -117,8 +233,6 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   const T* __restrict__ x0 = static_cast<const T*>(a.x0);
   const T* __restrict__ x1 = static_cast<const T*>(a.x1);
   const T* __restrict__ wp = static_cast<const T*>(a.w);
-  T* __restrict__ yout = static_cast<T*>(a.y);
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
@@ -276,111 +390,211 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
     });
   }
 
-  // ---- epilogue: bias / folded affine / ReLU, per-channel partial statistics, coalesced store ----
-  // The accumulator tile goes through LDS (free after the last barrier) so that the global stores are
-  // whole pixel rows: 16 B per lane, BN*sizeof(T) contiguous bytes per pixel, instead of 2-byte scatters.
-  constexpr int RS = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);   // out-tile row stride (bytes), bank-staggered
-  // the staging tile must not be larger than the main-loop LDS (it would cost a resident workgroup): big
-  // tiles are flushed in EP passes, one group of WM/EP wave rows at a time
-  constexpr int LDS_MAIN = 2 * NIMG * (A_BYTES + B_BYTES);
-  constexpr int EP = (BM * RS + WM * 2 * BN * 4 <= LDS_MAIN) ? 1 : ((BM / 2) * RS + WM * 2 * BN * 4 <= LDS_MAIN ? 2 : 4);
-  static_assert(WM % EP == 0 || EP == 1, "epilogue passes split the wave rows");
-  constexpr int PM = BM / EP;                                         // pixels per pass
-  char* const otile = smem;                                           // [PM][RS]
-  float* const red = reinterpret_cast<float*>(smem + PM * RS);       // [WM][2][BN]
-  const bool want_stats = a.stat_part != nullptr;
-  float s1[NI], s2[NI];
+  conv_epilogue<T, TH, TW, BN, WM, WN, 2 * NIMG * (A_BYTES + B_BYTES)>(a, acc, smem, img, y0, x0p, n0);
+}
+
+// =========================================================================================================
+// bf16 main loop v2: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPR staging.
+//   * LDS rows are 64 B (32 channels), unpadded because a DMA wave-instruction writes 1 KiB linearly
+//     (16 rows x 4 pieces); bank conflicts are removed by an XOR swizzle instead: piece p of row r is stored
+//     in slot p ^ ((r >> 2) & 3).  For the DMA this swizzle sits on the per-lane SOURCE address (lane l
+//     fetches piece (l & 3) ^ ((l >> 4) & 3)); the fragment reads apply the same XOR.  Any 16 consecutive
+//     rows then cover the 16 slots of the 256-B bank row exactly once.
+//   * zero padding / ragged edges: out-of-range lanes fetch from a 64-B zero page instead of being masked, so
+//     every wave issues the same number of DMA instructions and the counted s_waitcnt vmcnt(N) is exact.
+//   * weight slabs stream through an NS-slot ring, NS-1 taps ahead of their use; the halo of the next
+//     32-channel chunk is fetched during the current chunk.  One raw s_barrier per tap; DMAs stay in flight
+//     across it (a __syncthreads() would drain them).
+// =========================================================================================================
+__device__ __attribute__((aligned(64))) char g_zero_page[64];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
+  using T = bf16_t;
+  constexpr int HW_ = TW + 2, HH_ = TH + 2, HALO = HW_ * HH_;
+  constexpr int NGA = (HALO + 15) / 16, HG = (NGA + 3) / 4;   // halo row groups, DMA instr per wave
+  constexpr int A_BYTES = HG * 4 * 1024;
+  constexpr int BG = BN / 64;                                 // weight DMA instr per wave per slab
+  constexpr int B_BYTES = BN * 64;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  static_assert(WM * WN == 4 && BN % 64 == 0 && (NS == 3 || NS == 4), "configuration");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;                    // [2][A_BYTES]
+  char* const ldsB = smem + 2 * A_BYTES;      // [NS][B_BYTES]
+
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+  const T* __restrict__ wp = static_cast<const T*>(a.w);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  int bt = blockIdx.x;
+  const int tx = bt % a.tilesX; bt /= a.tilesX;
+  const int ty = bt % a.tilesY;
+  const int img = bt / a.tilesY;
+  const int y0 = ty * TH, x0p = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  const int ctot = a.c0 + a.c1;
+
+  // ---- DMA lane geometry: lane -> (row in group, slot); the piece it fetches is slot ^ swizzle(row) ----
+  const int drow = lane >> 2;
+  const int dpiece = (lane & 3) ^ ((lane >> 4) & 3);
+  int apix[HG];    // NHWC pixel index of this lane's halo row in DMA group j, -1 = zero page
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
-#pragma unroll
-  for (int ep = 0; ep < EP; ++ep) {
-    if (ep > 0) __syncthreads();
-    if (wm / (WM / EP) == ep || EP == 1) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int nl = wn * WTN + ni * 32 + r;
-        const int n = n0 + nl;
-        const bool nok = n < a.Cout;
-        const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
-        const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
-        const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          float v[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-            const int m = wm * WTM + mi * 32 + row;
-            const int py = m / TW, px = m - py * TW;
-            float t = acc[mi][ni][j] + bias;
-            if (a.ep_scale) t = t * esc + esh;
-            if (a.relu) t = fmaxf(t, 0.f);
-            v[j] = t;
-            if (nok && y0 + py < a.H && x0p + px < a.W) { s1[ni] += t; s2[ni] += t * t; }
-          }
-          const int mrow0 = wm * WTM + mi * 32 + 4 * h - ep * PM;
-          if constexpr (SPLIT) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-              *reinterpret_cast<float*>(otile + (mrow0 + (j & 3) + 8 * (j >> 2)) * RS + nl * 4) = v[j];
-          } else {
-            // lanes (2k, 2k+1) hold channels (n, n+1) of the same rows: swap so each lane owns a channel
-            // PAIR of one row and writes one dword -- even lane row j, odd lane row j+1
-            const bool odd = lane & 1;
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-              const float got = __shfl_xor(odd ? v[j] : v[j + 1], 1, 64);
-              bf16x2 pk;
-              pk[0] = (bf16_t)(odd ? got : v[j]);
-              pk[1] = (bf16_t)(odd ? v[j + 1] : got);
-              const int mr = mrow0 + ((j + (odd ? 1 : 0)) & 3) + 8 * (j >> 2);
-              *reinterpret_cast<bf16x2*>(otile + mr * RS + (nl & ~1) * 2) = pk;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-B chunk
-    constexpr int CPR = BN / EPC;                     // chunks per pixel row
-    constexpr int O_IT = (PM * CPR + 255) / 256;
-#pragma unroll
-    for (int i = 0; i < O_IT; ++i) {
-      const int idx = tid + i * 256;
-      const int ml = idx / CPR, c = idx - ml * CPR;
-      const int m = ml + ep * PM;
-      const int py = m / TW, px = m - py * TW;
-      const int gy = y0 + py, gx = x0p + px, n = n0 + c * EPC;
-      if (idx < PM * CPR && gy < a.H && gx < a.W && n < a.Cout) {
-        const f32x4 val = *reinterpret_cast<const f32x4*>(otile + ml * RS + c * 16);
-        *reinterpret_cast<f32x4*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
-      }
-    }
+  for (int j = 0; j < HG; ++j) {
+    const int px = (wave + 4 * j) * 16 + drow;
+    const int hy = px / HW_, hx = px - hy * HW_;
+    const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+    apix[j] = (px < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (img * a.H + gy) * a.W + gx : -1;
   }
-  if (want_stats) {
+  int wrow[BG];    // element offset of this lane's weight row piece inside a slab, -1 = zero page
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int nl = wn * WTN + ni * 32 + r;
-      const float t1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
-      const float t2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + nl] = t1;
-        red[(wm * 2 + 1) * BN + nl] = t2;
-      }
-    }
-    __syncthreads();
+  for (int j = 0; j < BG; ++j) {
+    const int n = (wave + 4 * j) * 16 + drow;
+    wrow[j] = (n0 + n < a.Cout) ? (n0 + n) * 32 + dpiece * 8 : -1;
   }
-  if (want_stats) {
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int which = i / BN, nl = i - which * BN;
-      if (n0 + nl < a.Cout) {
-        float s = 0.f;
+
+  auto dma_halo = [&](int c) {
+    char* dst = ldsA + (c & 1) * A_BYTES;
+    const int ch = c * 32 + dpiece * 8;
 #pragma unroll
-        for (int k = 0; k < WM; ++k) s += red[(k * 2 + which) * BN + nl];
-        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = s;
+    for (int j = 0; j < HG; ++j) {
+      const void* g = g_zero_page;
+      if (apix[j] >= 0) {
+        if (ch < a.c0) g = x0 + (long)apix[j] * a.ld0 + ch;
+        else if (ch < ctot) g = x1 + (long)apix[j] * a.ld1 + (ch - a.c0);
       }
+      dma16(g, dst + (wave + 4 * j) * 1024);
     }
+  };
+  auto dma_w = [&](int it, int slot) {
+    const int c = it / 9, tap = it - c * 9;
+    const T* base = wp + ((long)(tap * a.nchunk + c) * a.Cout) * 32;
+    char* dst = ldsB + slot * B_BYTES;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      const void* g = wrow[j] >= 0 ? (const void*)(base + wrow[j]) : (const void*)g_zero_page;
+      dma16(g, dst + (wave + 4 * j) * 1024);
+    }
+  };
+
+  // ---- fragment geometry ----
+  int apx[MI];     // halo row of this lane's pixel for tap (0,0)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 32 + r;
+    const int py = m / TW, px = m - py * TW;
+    apx[mi] = py * HW_ + px;
   }
+  int bofs[NI];    // byte offset of this lane's weight row, k-step 0, swizzled
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = wn * WTN + ni * 32 + r;
+    bofs[ni] = n * 64 + ((h ^ ((n >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+
+  const int nit = a.nchunk * 9;
+
+  // ---- prologue: halo 0 and the first NS-1 slabs ----
+  dma_halo(0);
+#pragma unroll
+  for (int k = 0; k < NS - 1; ++k)
+    if (k < nit) dma_w(k, k);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  for (int c = 0; c < a.nchunk; ++c) {
+    const bool more = c + 1 < a.nchunk;
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    static_for<9>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      const int it = c * 9 + tap;
+      // issue: next chunk's halo (once per chunk), then the slab NS-1 taps ahead; its slot was read one tap ago
+      if (tap == 0 && more) dma_halo(c + 1);
+      if (it + NS - 1 < nit) dma_w(it + NS - 1, (it + NS - 1) % NS);
+      const char* Bb = ldsB + (it % NS) * B_BYTES;
+      constexpr int tappx = (tap / 3) * HW_ + (tap % 3);
+      int aofs[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int px = apx[mi] + tappx;
+        aofs[mi] = px * 64 + ((h ^ ((px >> 2) & 3)) << 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(Ab + (aofs[mi] ^ (ks << 5)));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + (bofs[ni] ^ (ks << 5)));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+      // retire slab it+1 (and, early in a chunk, keep the just-issued halo in flight): everything issued
+      // after it may stay outstanding -- (NS-2) slabs, plus the halo while it is younger than slab it+1
+      if (it + NS - 1 >= nit) {
+        wait_vm<0>();
+      } else if (tap <= NS - 3 && more) {
+        wait_vm<(NS - 2) * BG + HG>();
+      } else {
+        wait_vm<(NS - 2) * BG>();
+      }
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  conv_epilogue<T, TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES>(a, acc, smem, img, y0, x0p, n0);
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int NS>
+int launch_dma(Conv3x3Args& a, hipStream_t s) {
+  constexpr int HALO = (TH + 2) * (TW + 2);
+  constexpr int HG = ((HALO + 15) / 16 + 3) / 4;
+  constexpr int lds_main = 2 * HG * 4 * 1024 + NS * BN * 64;
+  constexpr int RS_ = BN * 2 + 64;
+  constexpr int red_ = WM * 2 * BN * 4;
+  constexpr int EP_ = (TH * TW * RS_ + red_ <= lds_main) ? 1 : ((TH * TW / 2) * RS_ + red_ <= lds_main ? 2 : 4);
+  constexpr int lds_epi = (TH * TW / EP_) * RS_ + red_;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  auto kern = conv3x3_dma_kernel<TH, TW, BN, WM, WN, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }
 
 template <typename T, int TH, int TW, int BN, int WM, int WN>
@@ -445,6 +659,20 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
     // three bf16 images per operand: small tiles so the double-buffered LDS still fits
     if (id == 1) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
     return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
+  }
+  static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 1; }();
+  if (use_dma) {
+    // the alignment the DMA path needs beyond the register-staged one: 16-B aligned pixel rows
+    switch (id) {
+      case 0: return use_dma == 3 ? launch_dma<8, 32, 128, 2, 2, 3>(a, s) : launch_dma<8, 32, 128, 2, 2, 4>(a, s);
+      case 1: return use_dma == 3 ? launch_dma<8, 32, 64, 4, 1, 3>(a, s) : launch_dma<8, 32, 64, 4, 1, 4>(a, s);
+      case 2: return use_dma == 3 ? launch_dma<4, 32, 128, 2, 2, 3>(a, s) : launch_dma<4, 32, 128, 2, 2, 4>(a, s);
+      case 3: return use_dma == 3 ? launch_dma<4, 32, 64, 2, 2, 3>(a, s) : launch_dma<4, 32, 64, 2, 2, 4>(a, s);
+      case 4: return use_dma == 3 ? launch_dma<16, 16, 128, 2, 2, 3>(a, s) : launch_dma<16, 16, 128, 2, 2, 4>(a, s);
+      case 5: return use_dma == 3 ? launch_dma<16, 16, 64, 4, 1, 3>(a, s) : launch_dma<16, 16, 64, 4, 1, 4>(a, s);
+      case 6: return use_dma == 3 ? launch_dma<8, 16, 128, 2, 2, 3>(a, s) : launch_dma<8, 16, 128, 2, 2, 4>(a, s);
+      case 7: return use_dma == 3 ? launch_dma<8, 16, 64, 2, 2, 3>(a, s) : launch_dma<8, 16, 64, 2, 2, 4>(a, s);
+    }
   }
   switch (id) {
     case 0: return launch_cfg<bf16_t, 8, 32, 128, 2, 2>(a, s);
