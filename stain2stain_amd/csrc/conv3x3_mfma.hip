@@ -5,7 +5,7 @@
 // the data-gradient of the same layers in the backward pass (same kernel, weights packed
 // flipped/transposed by s2s_pack_conv3x3).
 //
-// Decomposition: D[pixel][cout] = sum_{tap, cin} X[pixel (+) tap][cin] * Wp[tap][cout][cin]
+// Decomposition: D[pixel][cout] = sum_{tap, cin} X[pixel (+) tap][cin] * Wp[cin/32][tap][cout][32]
 //   * one workgroup (256 threads = 4 waves) owns a TH x TW spatial tile of one image and BN output
 //     channels; the accumulators (fp32) live in registers for the whole K loop.
 //   * K loop: input channels in chunks of 32.  Per chunk the (TH+2) x (TW+2) x 32 halo patch is
@@ -35,7 +35,7 @@
 struct Conv3x3Args {
   const void* x0;
   const void* x1;
-  const void* w;        // packed [9][nchunk][Cout][32]
+  const void* w;        // packed [nchunk][9][Cout][32]
   const float* bias;    // [Cout] or null
   void* y;
   float* stat_part;     // [gridDim.x][2][Cout] or null
@@ -44,6 +44,7 @@ struct Conv3x3Args {
   int ld0, c0, ld1, c1, ldy;
   int B, H, W, Cout, tilesY, tilesX, nchunk;
   int relu;
+  int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
 };
 
 namespace {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   auto load_w = [&](int it, auto setc) {
     constexpr int set = decltype(setc)::value;
     const int c = it / 9, tap = it - c * 9;
-    const T* base = wp + ((long)(tap * a.nchunk + c) * a.Cout) * 32;
+    const T* base = wp + ((long)it * a.Cout) * 32;   // slabs are packed in iteration order [chunk][tap]
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int idx = tid + i * 256;
@@ -422,8 +423,11 @@ __device__ __forceinline__ void wait_vm() {
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
   using T = bf16_t;
-  constexpr int HW_ = TW + 2, HH_ = TH + 2, HALO = HW_ * HH_;
-  constexpr int NGA = (HALO + 15) / 16, HG = (NGA + 3) / 4;   // halo row groups, DMA instr per wave
+  // halo image: row index = hy * HP + hx with the pitch HP = TW + 4 a multiple of 4, so that the bank-row phase
+  // (row & 3) equals hx & 3 and the swizzle can be keyed on hx alone: slot = piece ^ ((hx >> 2) & 3).  A tap's
+  // kh then is a constant byte offset (folded into the ds_read immediate) and only kw changes the swizzle.
+  constexpr int HP = TW + 4, HH_ = TH + 2, ROWS = HH_ * HP;
+  constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + 3) / 4;   // halo row groups, DMA instr per wave
   constexpr int A_BYTES = HG * 4 * 1024;
   constexpr int BG = BN / 64;                                 // weight DMA instr per wave per slab
   constexpr int B_BYTES = BN * 64;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
 
   const T* __restrict__ x0 = static_cast<const T*>(a.x0);
   const T* __restrict__ x1 = static_cast<const T*>(a.x1);
-  const T* __restrict__ wp = static_cast<const T*>(a.w);
+  const char* __restrict__ wp = static_cast<const char*>(a.w);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,57 +455,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
   const int n0 = blockIdx.y * BN;
   const int ctot = a.c0 + a.c1;
 
-  // ---- DMA lane geometry: lane -> (row in group, slot); the piece it fetches is slot ^ swizzle(row) ----
-  const int drow = lane >> 2;
-  const int dpiece = (lane & 3) ^ ((lane >> 4) & 3);
+  // ---- DMA lane geometry ----
+  const int drow = lane >> 2, dslot = lane & 3;
   int apix[HG];    // NHWC pixel index of this lane's halo row in DMA group j, -1 = zero page
+  int apc[HG];     // channel offset (elements) inside a 32-channel chunk of the piece this lane fetches
 #pragma unroll
   for (int j = 0; j < HG; ++j) {
-    const int px = (wave + 4 * j) * 16 + drow;
-    const int hy = px / HW_, hx = px - hy * HW_;
+    const int row = (wave + 4 * j) * 16 + drow;
+    const int hy = row / HP, hx = row - hy * HP;
     const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-    apix[j] = (px < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (img * a.H + gy) * a.W + gx : -1;
+    apix[j] = (row < ROWS && hx < TW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                  ? (img * a.H + gy) * a.W + gx : -1;
+    apc[j] = (dslot ^ ((hx >> 2) & 3)) * 8;
   }
-  int wrow[BG];    // element offset of this lane's weight row piece inside a slab, -1 = zero page
+  // weights: slab `it` = [Cout][32] at byte offset it * Cout * 64; every lane keeps a running pointer to its
+  // row piece (rows past Cout park on the zero page with a zero stride)
+  const char* wptr[BG];
+  int wstep[BG];
 #pragma unroll
   for (int j = 0; j < BG; ++j) {
     const int n = (wave + 4 * j) * 16 + drow;
-    wrow[j] = (n0 + n < a.Cout) ? (n0 + n) * 32 + dpiece * 8 : -1;
+    const bool ok = n0 + n < a.Cout;
+    wptr[j] = ok ? wp + ((long)(n0 + n) * 32 + ((dslot ^ ((n >> 2) & 3)) * 8)) * 2 : g_zero_page;
+    wstep[j] = ok ? a.Cout * 64 : 0;
   }
 
   auto dma_halo = [&](int c) {
-    char* dst = ldsA + (c & 1) * A_BYTES;
-    const int ch = c * 32 + dpiece * 8;
+    char* dst = ldsA + (c & 1) * A_BYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < HG; ++j) {
+      const int ch = c * 32 + apc[j];
       const void* g = g_zero_page;
       if (apix[j] >= 0) {
         if (ch < a.c0) g = x0 + (long)apix[j] * a.ld0 + ch;
         else if (ch < ctot) g = x1 + (long)apix[j] * a.ld1 + (ch - a.c0);
       }
-      dma16(g, dst + (wave + 4 * j) * 1024);
+      dma16(g, dst + j * 4096);
     }
   };
-  auto dma_w = [&](int it, int slot) {
-    const int c = it / 9, tap = it - c * 9;
-    const T* base = wp + ((long)(tap * a.nchunk + c) * a.Cout) * 32;
-    char* dst = ldsB + slot * B_BYTES;
+  auto dma_w = [&](int slot) {   // next slab in sequence
+    char* dst = ldsB + slot * B_BYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
-      const void* g = wrow[j] >= 0 ? (const void*)(base + wrow[j]) : (const void*)g_zero_page;
-      dma16(g, dst + (wave + 4 * j) * 1024);
+      dma16(wptr[j], dst + j * 4096);
+      wptr[j] += wstep[j];
     }
   };
 
-  // ---- fragment geometry ----
-  int apx[MI];     // halo row of this lane's pixel for tap (0,0)
+  // ---- fragment geometry (computed once) ----
+  int aofs[MI][3];   // byte offset of this lane's pixel row for tap (0, kw), k-step 0
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WTM + mi * 32 + r;
     const int py = m / TW, px = m - py * TW;
-    apx[mi] = py * HW_ + px;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+      aofs[mi][kw] = (py * HP + px + kw) * 64 + ((h ^ (((px + kw) >> 2) & 3)) << 4);
   }
-  int bofs[NI];    // byte offset of this lane's weight row, k-step 0, swizzled
+  int bofs[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = wn * WTN + ni * 32 + r;
@@ -516,55 +527,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
-  const int nit = a.nchunk * 9;
-
-  // ---- prologue: halo 0 and the first NS-1 slabs ----
-  dma_halo(0);
+  // one tap: MFMAs of tap `tap` from halo buffer Ab and weight slot (it % NS)
+  auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int kh = tap / 3, kw = tap % 3;
 #pragma unroll
-  for (int k = 0; k < NS - 1; ++k)
-    if (k < nit) dma_w(k, k);
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const bf16x8*>(Ab + (aofs[mi][kw] ^ (ks << 5)) + kh * HP * 64);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + (bofs[ni] ^ (ks << 5)));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: halo 0 and the first NS-1 slabs (slabs past the end are harmless: they read the next
+  //      chunk's bytes of the packed weights only if they exist, so clamp by count) ----
+  const int nit = a.nchunk * 9;
+  dma_halo(0);
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });   // nit >= 9 > NS-1
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  for (int c = 0; c < a.nchunk; ++c) {
-    const bool more = c + 1 < a.nchunk;
+  // ---- steady state: every chunk but the last; no run-time conditions inside a tap ----
+  int c = 0;
+  for (; c + 1 < a.nchunk; ++c) {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * 9;
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
-      const int it = c * 9 + tap;
-      // issue: next chunk's halo (once per chunk), then the slab NS-1 taps ahead; its slot was read one tap ago
-      if (tap == 0 && more) dma_halo(c + 1);
-      if (it + NS - 1 < nit) dma_w(it + NS - 1, (it + NS - 1) % NS);
-      const char* Bb = ldsB + (it % NS) * B_BYTES;
-      constexpr int tappx = (tap / 3) * HW_ + (tap % 3);
-      int aofs[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int px = apx[mi] + tappx;
-        aofs[mi] = px * 64 + ((h ^ ((px >> 2) & 3)) << 4);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[MI], bfr[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(Ab + (aofs[mi] ^ (ks << 5)));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + (bofs[ni] ^ (ks << 5)));
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
-      }
-      // retire slab it+1 (and, early in a chunk, keep the just-issued halo in flight): everything issued
-      // after it may stay outstanding -- (NS-2) slabs, plus the halo while it is younger than slab it+1
-      if (it + NS - 1 >= nit) {
-        wait_vm<0>();
-      } else if (tap <= NS - 3 && more) {
-        wait_vm<(NS - 2) * BG + HG>();
-      } else {
-        wait_vm<(NS - 2) * BG>();
-      }
+      if (tap == 0) { if (!(a.dbg & 4)) dma_halo(c + 1); else { static_for<HG>([&](auto) { dma16(g_zero_page, ldsA + ((c + 1) & 1) * A_BYTES + wave * 1024); }); } }
+      if (!(a.dbg & 1)) dma_w((it0 + tap + NS - 1) % NS);            // the slot read one tap ago
+      else { static_for<BG>([&](auto) { dma16(g_zero_page, ldsB + wave * 1024); }); }
+      if (!(a.dbg & 2)) compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);           // this tap's MFMAs (and LDS reads) stay ahead of the barrier
+      // retire slab it+1: the (NS-2) younger slabs, and the halo while it is younger, may stay in flight
+      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  // ---- last chunk: no further halo; slabs run out NS-1 taps before the end ----
+  {
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * 9;
+    static_for<9>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap + NS - 1 < 9) dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + NS - 1 < 9) wait_vm<(NS - 2) * BG>(); else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
     });
   }
@@ -573,8 +590,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 int launch_dma(Conv3x3Args& a, hipStream_t s) {
-  constexpr int HALO = (TH + 2) * (TW + 2);
-  constexpr int HG = ((HALO + 15) / 16 + 3) / 4;
+  constexpr int ROWS = (TH + 2) * (TW + 4);
+  constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
   constexpr int lds_main = 2 * HG * 4 * 1024 + NS * BN * 64;
   constexpr int RS_ = BN * 2 + 64;
   constexpr int red_ = WM * 2 * BN * 4;
@@ -715,6 +732,7 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
+  { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   return dispatch(dtype, a, s);

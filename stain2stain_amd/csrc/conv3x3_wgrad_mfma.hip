@@ -19,6 +19,7 @@
 //     the OIHW fp32 gradient the optimiser sees.
 //   * T = float: three-way bf16 split of both operands, 6 MFMAs per product (see conv3x3_mfma.hip).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 struct WgradArgs {
@@ -219,6 +220,135 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   }
 }
 
+// =========================================================================================================
+// bf16 v2: the same computation with LDS-DMA staging (global_load_lds_dwordx4) and double-buffered LDS.
+// The [pixel][32 ch] images are already the linear layout a DMA wave-instruction writes (16 rows x 64 B),
+// so nothing changes on the read side; out-of-range rows fetch a zero page so that every wave issues the
+// same 10 DMAs per tile.  One barrier per pixel tile; the next tile's DMAs fly during the current MFMAs.
+// =========================================================================================================
+__device__ __attribute__((aligned(64))) char g_wgrad_zero_page[64];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// LDS-DMA issued from inline asm: hipcc's waitcnt pass does not see it, so it cannot put a conservative
+// s_waitcnt vmcnt(0) in front of the transposed LDS reads that follow (it does for the builtin form, which
+// serialises load and compute); completion is tracked by the explicit vmcnt waits below.  M0 carries the
+// wave-uniform LDS destination and is restored inside the same statement.
+__device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NPX = TH * TW;                             // 128
+  constexpr int HW_ = TW + 2, HALO = (TH + 2) * HW_;       // 180
+  constexpr int XROWS = (HALO + 15) / 16 * 16;             // 192 (padded to whole DMA groups)
+  constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
+  constexpr int DYG = 2 * NPX / 16 / 4;                    // dY DMA instr per wave (4)
+  constexpr int XG = 2 * XROWS / 16 / 4;                   // halo DMA instr per wave (6)
+  constexpr int BUF = DY_BYTES + X_BYTES;
+  constexpr int KSTEPS = NPX / 16;
+  static_assert((2 * NPX / 16) % 4 == 0 && (2 * XROWS / 16) % 4 == 0, "DMA groups split evenly over 4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0 + a.c1;
+  const int drow = lane >> 2, dslot = lane & 3;
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  auto dma_tile = [&](int tile, int buf) {
+    int bt = tile;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int img = bt / a.tilesY;
+    const int y0 = ty * TH, xs = tx * TW;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < DYG; ++j) {
+      const int grp = wave + 4 * j;                  // 0..15: half = grp / 8, rows (grp % 8) * 16 ..
+      const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
+      const int py = px / TW, pxx = px - py * TW;
+      const int gy = y0 + py, gx = xs + pxx, co = co0 + half * 32 + dslot * 8;
+      const void* src = g_wgrad_zero_page;
+      if (gy < a.H && gx < a.W && co < a.Cout) src = dy + ((long)(img * a.H + gy) * a.W + gx) * a.lddy + co;
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + grp * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < XG; ++j) {
+      const int grp = wave + 4 * j;                  // 0..23: half = grp / 12
+      const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
+      const int hy = px / HW_, hx = px - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = xs - 1 + hx, ci = ci0 + half * 32 + dslot * 8;
+      const void* src = g_wgrad_zero_page;
+      if (px < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const long pix = (long)(img * a.H + gy) * a.W + gx;
+        if (ci < a.c0) src = x0 + pix * a.ld0 + ci;
+        else if (ci < cin) src = x1 + pix * a.ld1 + (ci - a.c0);
+      }
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + grp * 1024));
+    }
+  };
+
+  int tile = blockIdx.z;
+  int buf = 0;
+  if (tile < a.ntiles) dma_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; tile < a.ntiles; tile += a.S) {
+    if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);   // lands during the MFMAs below
+    const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hoff = ((py + tap / 3) * HW_ + px + tap % 3) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
+      }
+    }
+    // every MFMA (hence every LDS read of this buffer) is issued before the barrier: the next iteration's DMA
+    // overwrites this buffer's sibling, the one after it this buffer
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (co < a.Cout && ci < cin)
+        a.part[(((long)blockIdx.z * 9 + tap) * a.Cout + co) * cin + ci] = acc[tap][j];
+    }
+  }
+}
+
 // grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci]; one thread per (co, ci, tap) with ci fastest across lanes
 // for the reads; the 9 taps of one (co,ci) are gathered through LDS so the OIHW store is contiguous.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
@@ -269,6 +399,27 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   return S2S_OK;
 }
 
+template <int TH, int TW>
+int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
+  constexpr int XROWS = ((TH + 2) * (TW + 2) + 15) / 16 * 16;
+  constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  a.ntiles = a.B * a.tilesY * a.tilesX;
+  if (a.S > a.ntiles) return S2S_ERR_SHAPE;
+  auto kern = conv3x3_wgrad_dma_kernel<TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 // one pixel tile = 8 rows x 16 columns (halo 10 x 18); this shape keeps the staging prefetch small
 // enough for two workgroups per CU (a 4 x 32 tile spills at that occupancy)
 int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
@@ -301,7 +452,8 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   a.S = s2s_conv3x3_wgrad_splits(B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
+  static const int use_dma = [] { const char* e = getenv("S2S_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+  if (dtype == S2S_BF16) rc = use_dma ? launch_wgrad_dma<8, 16>(a, s) : launch_wgrad<bf16_t, 8, 16>(a, s);
   else if (dtype == S2S_F32) rc = launch_wgrad<float, 8, 16>(a, s);
   else return S2S_ERR_DTYPE;
   if (rc != S2S_OK) return rc;

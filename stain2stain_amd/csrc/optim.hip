@@ -4,8 +4,8 @@
 //                       parameter buffer -- the optimiser the reference builds in configure_optimizers
 //                       (src/models/conditional_flow_matching.py:112-131, configs/model/*.yaml:3-7).
 //   s2s_pack_conv3x3    OIHW fp32 master weights -> the two MFMA operand layouts of conv3x3_mfma.hip:
-//                       forward  Wf[tap][cin/32][cout][32]  and data-gradient
-//                       Wd[tap'][cout/32][cin][32] = W[co][ci][2-kh'][2-kw'] (flipped, transposed).
+//                       forward  Wf[cin/32][tap][cout][32]  and data-gradient
+//                       Wd[cout/32][tap'][cin][32] = W[co][ci][2-kh'][2-kw'] (flipped, transposed); slabs in K-loop order.
 //   s2s_nchw_to_nhwc / s2s_nhwc_to_nchw   fp32 NCHW <-> NHWC(T) at the module boundary (the reference's
 //                       boundary layout is NCHW contiguous fp32).
 #include "common.h"
@@ -39,8 +39,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
       const int k = (int)(i & 31);
       long t = i >> 5;
       const int co = (int)(t % Cout); t /= Cout;
-      const int c = (int)(t % nci);
-      const int tap = (int)(t / nci);
+      const int tap = (int)(t % 9);
+      const int c = (int)(t / 9);
       const int ci = c * 32 + k;
       wf[i] = from_f32<T>(ci < Cin ? w[((long)co * Cin + ci) * 9 + tap] : 0.f);
     } else if (wd) {
@@ -48,8 +48,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
       const int k = (int)(j & 31);
       long t = j >> 5;
       const int ci = (int)(t % Cin); t /= Cin;
-      const int c = (int)(t % nco);
-      const int tap = (int)(t / nco);
+      const int tap = (int)(t % 9);
+      const int c = (int)(t / 9);
       const int co = c * 32 + k;
       wd[j] = from_f32<T>(co < Cout ? w[((long)co * Cin + ci) * 9 + (8 - tap)] : 0.f);
     }
