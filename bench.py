@@ -76,8 +76,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("S2S_FORCE_DDP") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from stain2stain_amd import CFMTrainer, FlowUNet, ops
@@ -94,7 +96,7 @@ def main() -> None:
     for i in range(args.warmup):
         trainer.step(x0, x1, ts[i])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_start()
@@ -103,12 +105,12 @@ def main() -> None:
     for i in range(args.steps):
         loss = trainer.step(x0, x1, ts[args.warmup + i])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_stop()
-    if world > 1:
+    if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el)
@@ -148,7 +150,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

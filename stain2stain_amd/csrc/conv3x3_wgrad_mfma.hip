@@ -432,7 +432,11 @@ extern "C" int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) 
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = wgrad_ntiles(B, H, W);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
-  int s = cdiv(320, mn);   // ~320-512 workgroups: enough to fill 256 CUs twice, few enough partial slabs
+  static const int target = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
+  // slab, so the few-channel layers (mn = 1..2) stop at 320 splits
+  int s = target / mn;
+  if (s > 320) s = 320;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
   return s;

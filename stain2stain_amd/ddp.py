@@ -14,6 +14,7 @@ Pure host logic over ``torch.distributed``: works with the ``nccl`` (= RCCL) bac
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -44,7 +45,9 @@ class GradBucketer:
                  process_group: Optional[dist.ProcessGroup] = None):
         self.flat = flat_grad
         self.pg = process_group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # S2S_FORCE_DDP=1 issues the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or os.environ.get("S2S_FORCE_DDP") == "1")
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         if sum(group_sizes) != flat_grad.numel():
             raise ValueError("group sizes do not cover the flat gradient buffer")
@@ -78,9 +81,14 @@ class GradBucketer:
         self._works = []
 
 
+def _active(process_group) -> bool:
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(process_group) > 1 or os.environ.get("S2S_FORCE_DDP") == "1")
+
+
 def broadcast_from_rank0(tensors: Sequence[torch.Tensor], process_group=None) -> None:
     """Initial replica synchronisation (what torch DDP does at construction)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    if not _active(process_group):
         return
     for t in tensors:
         dist.broadcast(t, src=0, group=process_group)
@@ -88,6 +96,6 @@ def broadcast_from_rank0(tensors: Sequence[torch.Tensor], process_group=None) ->
 
 def all_reduce_mean_scalar(x: torch.Tensor, process_group=None):
     """``self.log(..., sync_dist=True)`` of the reference (conditional_flow_matching.py:86): mean over ranks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    if not _active(process_group):
         return None
     return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
