@@ -67,6 +67,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (default: the headline 16)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true",
+                    help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +101,8 @@ def main() -> None:
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.profile_start()
+    # live HIP-event timing of the dominant kernels only (every launch of the timed region)
+    ops.profile_start(None if args.breakdown else ("conv3x3_mfma", "conv3x3_wgrad_mfma"))
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):

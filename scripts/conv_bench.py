@@ -40,10 +40,10 @@ for (H, c0, c1, cout) in FWD:
     dx = torch.empty(B, H, H, cin, device=dev, dtype=dt)
     grad = torch.empty(cout, cin, 3, 3, device=dev)
     row = f"H{H:4d} cin{cin:5d} cout{cout:5d} {gflop:8.1f} GF |"
-    if which in ("all", "fwd"):
+    if which in ("all", "fwd", "fd"):
         t = timeit(lambda: ops.conv3x3(x0, x1, wf, bias, cout, want_stats=True, out=y))
         row += f" fwd {t*1e3:7.1f} us {gflop/t:7.0f} TF |"; tot["fwd"][0] += gflop; tot["fwd"][1] += t
-    if which in ("all", "dgrad"):
+    if which in ("all", "dgrad", "fd"):
         t = timeit(lambda: ops.conv3x3(dy, None, wd, None, cin, out=dx))
         row += f" dgrad {t*1e3:7.1f} us {gflop/t:7.0f} TF |"; tot["dgrad"][0] += gflop; tot["dgrad"][1] += t
     if which in ("all", "wgrad"):

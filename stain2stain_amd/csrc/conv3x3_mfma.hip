@@ -662,7 +662,7 @@ int select_cfg(int dtype, int B, int H, int W, int Cout) {
   long best_blocks = -1;
   for (int i = first; i < first + 4; ++i) {
     const TileCfg& c = kBf16Cfg[i];
-    if (c.bn == 128 && Cout <= 64) continue;
+    if (c.bn == 128 && (Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512))) continue;   // half-empty N tile
     const long nb = cfg_blocks(c, B, H, W, Cout);
     if (nb >= kMinBlocks) return i;
     if (nb > best_blocks) { best_blocks = nb; best = i; }

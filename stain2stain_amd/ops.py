@@ -68,11 +68,15 @@ def _L():
 # optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
 # ------------------------------------------------------------------------------------------------
 _PROFILE: Optional[list] = None
+_PROFILE_ONLY: Optional[set] = None
 
 
-def profile_start() -> None:
-    global _PROFILE
+def profile_start(only=None) -> None:
+    """Record HIP events around op launches; ``only`` restricts it to the named ops (cheaper: an event pair
+    costs a few microseconds of host time per launch)."""
+    global _PROFILE, _PROFILE_ONLY
     _PROFILE = []
+    _PROFILE_ONLY = set(only) if only else None
 
 
 def profile_stop() -> list:
@@ -85,7 +89,7 @@ def profile_stop() -> list:
 def _timed(name: str, work_fn=None):
     def deco(fn):
         def wrapped(*args, **kwargs):
-            if _PROFILE is None:
+            if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
                 return fn(*args, **kwargs)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
