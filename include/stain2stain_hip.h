@@ -89,10 +89,11 @@ int s2s_bn_relu_apply(int dtype, const void* x, int ldx, const float* scale, con
 int s2s_maxpool2(int dtype, const void* x, int ldx, void* pool, int ldp, int B, int H, int W, int C, void* stream);
 int s2s_bn_bwd_blocks(int B, int H, int W, int C);
 /* g1: gradient wrt the ReLU output (may be NULL if gp given); gp: gradient wrt the pooled output (may be
- * NULL); y/x: saved ReLU output / conv output; work: float[4*blocks*C + 2*C];
+ * NULL); scale/shift: the forward's folded affine (the ReLU output is recomputed from x, not read);
+ * x: saved conv output; work: float[4*blocks*C + 2*C];
  * dbias_conv (optional): gradient of the preceding conv's bias = per-channel sum of dx. */
-int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const void* y, int ldy,
-                    const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
+                    const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                     float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx, float* work, int B, int H,
                     int W, int C, void* stream);
 

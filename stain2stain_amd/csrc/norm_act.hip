@@ -99,7 +99,7 @@ __global__ void bn_relu_apply_kernel(const T* __restrict__ x, int ldx, const flo
           f32x8 v = load8(x + pix * ldx + c8);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            v.v[k] = fmaxf(v.v[k] * sc[k] + sh[k], 0.f);
+            v.v[k] = fmaxf(fmaf(v.v[k], sc[k], sh[k]), 0.f);   // the backward recomputes exactly this expression
             // pool on the value as stored (bf16-rounded in bf16 mode) so backward can recompute argmax
             const float st = to_f32(from_f32<T>(v.v[k]));
             mx[k] = fmaxf(mx[k], st);
@@ -155,8 +155,12 @@ struct WindowGrad {
   float dz[4][8];    // g * (y > 0)
   float xh[4][8];    // normalised conv output
   bool ok[4];
+  // The ReLU output is not read back: y = relu(x*scale+shift) is recomputed from the saved conv output with the
+  // forward's exact fp32 expression (and rounded to the storage type like the forward did), so the mask and the
+  // pool winner are bit-identical to the forward's while the backward moves 2 B/element less per pass.
   __device__ __forceinline__ void load(const T* __restrict__ g1, int ldg1, const T* __restrict__ gp, int ldgp,
-                                       const T* __restrict__ y, int ldy, const T* __restrict__ x, int ldx,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       const T* __restrict__ x, int ldx,
                                        const float* mean, const float* invstd, int n, int wy, int wx, int H,
                                        int W, int c8) {
     const int Hp = H >> 1, Wp = W >> 1;
@@ -167,13 +171,12 @@ struct WindowGrad {
       ok[q] = yy < H && xx < W;
       if (ok[q]) {
         const long pix = ((long)n * H + yy) * W + xx;
-        const f32x8 a = load8(y + pix * ldy + c8);
         const f32x8 b = load8(x + pix * ldx + c8);
         f32x8 g;
         if (g1) g = load8(g1 + pix * ldg1 + c8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          yv[q][k] = a.v[k];
+          yv[q][k] = to_f32(from_f32<T>(fmaxf(fmaf(b.v[k], scale[c8 + k], shift[c8 + k]), 0.f)));
           xh[q][k] = (b.v[k] - mean[c8 + k]) * invstd[c8 + k];
           dz[q][k] = g1 ? g.v[k] : 0.f;
         }
@@ -215,7 +218,7 @@ __device__ __forceinline__ int pcb_of(int C) {
 
 // partial[blk][2][C]: sum dz, sum dz*xhat.  grid = (channel groups, nblk)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const float* scale, const float* shift,
                                           const T* x, int ldx, const float* mean, const float* invstd,
                                           float* part, int B, int H, int W, int C) {
   const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
       const int wy = (int)(t % Hw);
       const int n = (int)(t / Hw);
       WindowGrad<T> wg;
-      wg.load(g1, ldg1, gp, ldgp, y, ldy, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+      wg.load(g1, ldg1, gp, ldgp, scale, shift, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float a = 0.f, b = 0.f;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
 
 // dx = gamma*invstd*(dz - c1 - xhat*c2); optional partial sums of dx over pixels (conv-bias gradient)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const T* y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const float* scale, const float* shift,
                                          const T* x, int ldx, const float* mean, const float* invstd,
                                          const float* gamma, const float* c1, const float* c2, T* dx, int lddx,
                                          float* dxsum_part, int B, int H, int W, int C) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int
       const int wy = (int)(t % Hw);
       const int n = (int)(t / Hw);
       WindowGrad<T> wg;
-      wg.load(g1, ldg1, gp, ldgp, y, ldy, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+      wg.load(g1, ldg1, gp, ldgp, scale, shift, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (!wg.ok[q]) continue;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int
 
 // ---- flat variants (no max-pool gradient): one pixel x 8 channels per thread-iteration, pure streaming ----
 template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* __restrict__ g1, int ldg1, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* __restrict__ g1, int ldg1, const float* __restrict__ scale, const float* __restrict__ shift,
                                                const T* __restrict__ x, int ldx, const float* mean, const float* invstd,
                                                float* part, long npix, int C) {
   const int PCB = pcb_of(C), WL = 256 / PCB;
@@ -352,16 +355,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* _
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
   if (c8 < C) {
-    float mu[8], is[8];
+    float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k]; }
+    for (int k = 0; k < 8; ++k) { mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k]; sc[k] = scale[c8 + k]; sh[k] = shift[c8 + k]; }
     for (long p = (long)blockIdx.y * WL + wl; p < npix; p += (long)gridDim.y * WL) {
       const f32x8 g = load8(g1 + p * ldg1 + c8);
-      const f32x8 a = load8(y + p * ldy + c8);
       const f32x8 b = load8(x + p * ldx + c8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float dz = a.v[k] > 0.f ? g.v[k] : 0.f;
+        const float dz = fmaf(b.v[k], sc[k], sh[k]) > 0.f ? g.v[k] : 0.f;   // ReLU mask from the conv output
         s1[k] += (Acc)dz;
         s2[k] += (Acc)(dz * ((b.v[k] - mu[k]) * is[k]));
       }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* _
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __restrict__ g1, int ldg1, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __restrict__ g1, int ldg1, const float* __restrict__ scale, const float* __restrict__ shift,
                                               const T* __restrict__ x, int ldx, const float* mean, const float* invstd,
                                               const float* gamma, const float* c1, const float* c2, T* __restrict__ dx,
                                               int lddx, float* dxsum_part, long npix, int C) {
@@ -393,20 +395,19 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = 0.f;
   if (c8 < C) {
-    float ga[8], k1[8], k2[8], mu[8], is[8];
+    float ga[8], k1[8], k2[8], mu[8], is[8], sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k];
+      mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k]; sc[k] = scale[c8 + k]; sh[k] = shift[c8 + k];
       ga[k] = gamma[c8 + k] * is[k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k];
     }
     for (long p = (long)blockIdx.y * WL + wl; p < npix; p += (long)gridDim.y * WL) {
       const f32x8 g = load8(g1 + p * ldg1 + c8);
-      const f32x8 a = load8(y + p * ldy + c8);
       const f32x8 b = load8(x + p * ldx + c8);
       f32x8 o;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float dz = a.v[k] > 0.f ? g.v[k] : 0.f;
+        const float dz = fmaf(b.v[k], sc[k], sh[k]) > 0.f ? g.v[k] : 0.f;
         o.v[k] = ga[k] * (dz - k1[k] - ((b.v[k] - mu[k]) * is[k]) * k2[k]);
         s[k] += o.v[k];
       }
@@ -537,13 +538,14 @@ extern "C" int s2s_bn_bwd_blocks(int B, int H, int W, int C) {
 
 // Whole BN+ReLU(+pool scatter) backward: reduce -> finalize -> apply (-> conv-bias gradient).
 //   g1/gp : gradient wrt the ReLU output (dense or channel slice) / wrt the pooled output (may be null)
-//   y, x  : saved ReLU output and conv output;  work: float[2*blocks*2*C + 2*C]
-extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const void* y, int ldy,
-                               const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
+//   scale/shift: the forward's folded BN affine (y = relu(x*scale+shift) is recomputed, not read); x: saved conv output;
+//   work: float[4*blocks*C + 2*C]
+extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
+                               const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
                                float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx,
                                float* work, int B, int H, int W, int C, void* stream) {
-  if ((!g1 && !gp) || !y || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx || !work) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldy % 8) || (ldx % 8) || (lddx % 8) ||
+  if ((!g1 && !gp) || !scale || !shift || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx || !work) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) ||
       (g1 && (ldg1 % 8)) || (gp && (ldgp % 8)))
     return S2S_ERR_SHAPE;
   const int nb = red_blocks(B, H, W, C);
@@ -557,20 +559,20 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
 #define S2S_BN_BWD(TT)                                                                                             \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,   \
-                       ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                \
+                       ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                \
   } else {                                                                                                         \
     hipLaunchKernelGGL(bn_relu_bwd_reduce_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,             \
-                       (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
+                       scale, shift, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
   }                                                                                                                \
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, nb, C, count, dgamma,      \
                      dbeta, accumulate, c1, c2);                                                                   \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
-                       ldgp, (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
+                       ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
                        dbias_conv ? part2 : nullptr, B, H, W, C);                                                  \
   } else {                                                                                                         \
     hipLaunchKernelGGL(bn_relu_bwd_apply_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,              \
-                       (const TT*)y, ldy, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,           \
+                       scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,           \
                        dbias_conv ? part2 : nullptr, (long)B * H * W, C);                                          \
   }
   if (dtype == S2S_BF16) { S2S_BN_BWD(bf16_t) }

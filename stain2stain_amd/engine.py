@@ -138,7 +138,7 @@ def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool,
     dgamma = _g(grads, f"{p}.{i_bn}.weight")
     dbeta = _g(grads, f"{p}.{i_bn}.bias")
     dbias = _g(grads, f"{p}.{i_conv}.bias") if cb.conv.bias is not None else None
-    draw = ops.bn_relu_bwd(g1, gp, lc.act, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
+    draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
     dw = _g(grads, f"{p}.{i_conv}.weight")
     if stem:
         ops.stem_wgrad(draw, lc.x0, dw, None, accumulate)

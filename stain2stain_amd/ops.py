@@ -285,19 +285,20 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
 
 
 @_timed("bn_relu_bwd")
-def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], y: torch.Tensor, x: torch.Tensor,
+def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], x: torch.Tensor,
                 stats: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
                 dbias_conv: Optional[torch.Tensor], accumulate: bool = False) -> torch.Tensor:
-    """Returns dx (gradient wrt the conv output).  stats = bn_finalize() output (rows mean, invstd, ...)."""
-    B, H, W, C = y.shape
-    py, ldy = _nhwc(y)
+    """Returns dx (gradient wrt the conv output x).  stats = bn_finalize() output (rows mean, invstd, scale,
+    shift); the ReLU mask / pool winner are recomputed from x with the forward's scale and shift."""
+    B, H, W, C = x.shape
     px, ldx = _nhwc(x)
     p1, ld1 = (0, 8) if g1 is None else _nhwc(g1)
     p2, ld2 = (0, 8) if gp is None else _nhwc(gp)
-    dx = torch.empty((B, H, W, C), dtype=y.dtype, device=y.device)
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     nb = _L().s2s_bn_bwd_blocks(B, H, W, C)
-    work = torch.empty((4 * nb * C + 2 * C,), dtype=torch.float32, device=y.device)
-    rc = _L().s2s_bn_relu_bwd(_dt(y), p1, ld1, p2, ld2, py, ldy, px, ldx, stats[0].data_ptr(), stats[1].data_ptr(),
+    work = torch.empty((4 * nb * C + 2 * C,), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_bn_relu_bwd(_dt(x), p1, ld1, p2, ld2, stats[2].data_ptr(), stats[3].data_ptr(), px, ldx,
+                              stats[0].data_ptr(), stats[1].data_ptr(),
                               _f32(gamma), _f32(dgamma), _f32(dbeta), _f32(dbias_conv), int(accumulate),
                               dx.data_ptr(), C, _f32(work), B, H, W, C, _stream())
     _native.check(rc, "bn_relu_bwd")

@@ -195,7 +195,7 @@ def test_bn_relu_pool_forward_backward(dtype, hw):
     assert relerr(nchw(ya), y) < tol_act(dtype)
     assert relerr(nchw(pool), p) < tol_act(dtype)
     dgam = torch.empty(C, device=DEV); dbet = torch.empty(C, device=DEV); dbias = torch.empty(C, device=DEV)
-    dz = ops.bn_relu_bwd(nhwc(g1, dtype), nhwc(gp, dtype), ya, zs, st, gamma.detach().to(DEV), dgam, dbet, dbias)
+    dz = ops.bn_relu_bwd(nhwc(g1, dtype), nhwc(gp, dtype), zs, st, gamma.detach().to(DEV), dgam, dbet, dbias)
     assert relerr(nchw(dz), z.grad) < tol_act(dtype) * 2
     assert relerr(dgam.cpu(), gamma.grad) < 5e-3 if dtype == torch.bfloat16 else relerr(dgam.cpu(), gamma.grad) < 1e-4
     assert relerr(dbet.cpu(), beta.grad) < 5e-3 if dtype == torch.bfloat16 else relerr(dbet.cpu(), beta.grad) < 1e-4
