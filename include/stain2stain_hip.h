@@ -132,6 +132,9 @@ int s2s_adam_step(float* p, const float* g, float* m, float* v, long n, int step
 long s2s_pack_conv3x3_fwd_elems(int Cout, int Cin);
 long s2s_pack_conv3x3_dgrad_elems(int Cout, int Cin);
 int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, void* stream);
+/* every conv layer in one launch; desc = device int64[nlayers][6] {w_oihw, w_fwd, w_dgrad, Cout, Cin, first 32x32 tile};
+ * total = number of 32x32 (co,ci) tiles over all layers */
+int s2s_pack_conv3x3_batched(int dtype, const void* desc, int nlayers, long total, void* stream);
 int s2s_nchw_to_nhwc(int dtype, const float* x_nchw, void* y, int ldy, int B, int C, int H, int W, void* stream);
 int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accumulate, int B, int C, int H, int W,
                      void* stream);

@@ -60,6 +60,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
+constexpr int STEM_HALO_BYTES = 3 * 18 * 18 * 4;   // fp32 halo of a 16x16 tile, up to 3 input channels
 
 template <typename T> struct Piece;
 template <> struct Piece<bf16_t> {
@@ -640,6 +641,142 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
+// =========================================================================================================
+// stem: Conv3x3(pad 1) from the NCHW fp32 image (Cin*9 <= 32) on the same MFMA path.  The im2col patch of a
+// 16x16 pixel tile is built in LDS as a [256][32] image (k = ci*9 + tap), the weights as [BN][32]; one
+// K = 32 step per 32x32 block, then the common epilogue (bias, BatchNorm partial sums, coalesced NHWC store).
+// The layer is bound by writing its output; T = float uses the three-way bf16 split like the main kernels.
+// =========================================================================================================
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(Conv3x3Args a, const float* __restrict__ x,
+                                                        const float* __restrict__ w, int Cin) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 3 : 1;
+  constexpr int TH = 16, TW = 16, BM = 256, WM = 4, WN = 1, MI = 2, NI = BN / 32;
+  constexpr int P_BYTES = BM * ROWB, W_BYTES = BN * ROWB;
+  constexpr int LDS_MAIN = NIMG * (P_BYTES + W_BYTES) + STEM_HALO_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsP = smem;                                   // [NIMG][256][80 B]
+  char* const ldsW = smem + NIMG * P_BYTES;                  // [NIMG][BN][80 B]
+  float* const xl = reinterpret_cast<float*>(smem + NIMG * (P_BYTES + W_BYTES));   // [Cin][18][18]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int bt = blockIdx.x;
+  const int tx = bt % a.tilesX; bt /= a.tilesX;
+  const int ty = bt % a.tilesY;
+  const int img = bt / a.tilesY;
+  const int y0 = ty * TH, x0p = tx * TW, n0 = blockIdx.y * BN;
+  const int K = Cin * 9;
+  for (int i = tid; i < Cin * 324; i += 256) {
+    const int ci = i / 324, rr = i - ci * 324, hy = rr / 18, hx = rr - hy * 18;
+    const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
+    xl[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? x[(((long)img * Cin + ci) * a.H + gy) * a.W + gx] : 0.f;
+  }
+  for (int i = tid; i < BN * 4; i += 256) {          // weight rows, 8 k per piece
+    const int n = i >> 2, pc = i & 3;
+    Piece<float> pw;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kk = pc * 8 + k;
+      const float v = (n0 + n < a.Cout && kk < K) ? w[(long)(n0 + n) * K + kk] : 0.f;
+      if (k < 4) pw.a[k] = v; else pw.b[k - 4] = v;
+    }
+    if constexpr (SPLIT) pw.to_lds(ldsW, W_BYTES, n * ROWB + pc * 16);
+    else {
+      bf16x8 hv;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hv[k] = (bf16_t)(k < 4 ? pw.a[k] : pw.b[k - 4]);
+      *reinterpret_cast<bf16x8*>(ldsW + n * ROWB + pc * 16) = hv;
+    }
+  }
+  __syncthreads();
+  {                                                    // im2col row of pixel `tid`
+    const int py = tid >> 4, px = tid & 15;
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      Piece<float> pp;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = pc * 8 + k;
+        float v = 0.f;
+        if (kk < K) {
+          const int ci = kk / 9, t = kk - ci * 9;
+          v = xl[ci * 324 + (py + t / 3) * 18 + px + t % 3];
+        }
+        if (k < 4) pp.a[k] = v; else pp.b[k - 4] = v;
+      }
+      if constexpr (SPLIT) pp.to_lds(ldsP, P_BYTES, tid * ROWB + pc * 16);
+      else {
+        bf16x8 hv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hv[k] = (bf16_t)(k < 4 ? pp.a[k] : pp.b[k - 4]);
+        *reinterpret_cast<bf16x8*>(ldsP + tid * ROWB + pc * 16) = hv;
+      }
+    }
+  }
+  __syncthreads();
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 af[NIMG][MI], bfr[NIMG][NI];
+#pragma unroll
+    for (int im = 0; im < NIMG; ++im) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[im][mi] = *reinterpret_cast<const bf16x8*>(ldsP + im * P_BYTES + (wave * 64 + mi * 32 + r) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bfr[im][ni] = *reinterpret_cast<const bf16x8*>(ldsW + im * W_BYTES + (ni * 32 + r) * ROWB + ks * 32 + h * 16);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (SPLIT) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bfr[1][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][mi], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bfr[2][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bfr[1][ni], acc[mi][ni], 0, 0, 0);
+        }
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+      }
+  }
+  __syncthreads();
+  conv_epilogue<T, TH, TW, BN, WM, WN, LDS_MAIN>(a, acc, smem, img, y0, x0p, n0);
+}
+
+template <typename T>
+int launch_stem(Conv3x3Args& a, const float* x, const float* w, int Cin, hipStream_t s) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 3 : 1, BN = 64;
+  constexpr int lds_main = NIMG * (256 + BN) * ROWB + STEM_HALO_BYTES;
+  constexpr int RS_ = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);
+  constexpr int red_ = 4 * 2 * BN * 4;
+  constexpr int EP_ = (256 * RS_ + red_ <= lds_main) ? 1 : (128 * RS_ + red_ <= lds_main ? 2 : 4);
+  constexpr int lds_epi = (256 / EP_) * RS_ + red_;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  a.tilesY = cdiv(a.H, 16);
+  a.tilesX = cdiv(a.W, 16);
+  auto kern = stem_mfma_kernel<T, BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, x, w, Cin);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 // ---- tile configuration table -----------------------------------------------------------------------
 // The largest tile whose grid still gives every CU about two workgroups wins; small feature maps
 // (16x16 ... 32x32 at batch 16) fall through to smaller tiles so that the 256 CUs stay busy.
@@ -705,6 +842,20 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// stem forward, called from s2s_stem_conv3x3_fwd (conv_edge.hip); statistics rows = B * ceil(H/16) * ceil(W/16)
+int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
+                          float* stat_part, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+  Conv3x3Args a;
+  a.x0 = a.x1 = a.w = nullptr; a.bias = bias; a.y = y; a.stat_part = stat_part;
+  a.ep_scale = a.ep_shift = nullptr;
+  a.ld0 = a.c0 = a.ld1 = a.c1 = 0; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = 1; a.relu = 0; a.dbg = 0;
+  a.tilesX = a.tilesY = 0;
+  if (dtype == S2S_BF16) return launch_stem<bf16_t>(a, x_nchw, w_oihw, Cin, s);
+  if (dtype == S2S_F32) return launch_stem<float>(a, x_nchw, w_oihw, Cin, s);
+  return S2S_ERR_DTYPE;
+}
 
 // Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
 // (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.

@@ -368,29 +368,22 @@ __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* par
 
 }  // namespace
 
+// MFMA stem forward lives next to the shared epilogue in conv3x3_mfma.hip
+int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
+                          float* stat_part, int B, int H, int W, int Cin, int Cout, hipStream_t s);
+
 extern "C" int s2s_stem_stat_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
-  return (int)(((long)B * H * W + 255) / 256);
+  return B * cdiv(H, 16) * cdiv(W, 16);
 }
 
 extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y,
                                     int ldy, float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream) {
   if (!x_nchw || !w_oihw || !y) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > STEM_MAX_CIN || Cout <= 0 || (Cout % 8) || (ldy % 8))
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin * 9 > 32 || Cout <= 0 || (Cout % 8) || (ldy % 8))
     return S2S_ERR_SHAPE;
-  const int lds = (Cout * Cin * 9 + 8 * Cout) * 4;
-  if (lds > 64 * 1024) return S2S_ERR_SHAPE;
-  const int grid = s2s_stem_stat_blocks(B, H, W);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, x_nchw, w_oihw, bias, (bf16_t*)y, ldy,
-                       stat_part, B, H, W, Cin, Cout);
-  else if (dtype == S2S_F32)
-    hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, x_nchw, w_oihw, bias, (float*)y, ldy,
-                       stat_part, B, H, W, Cin, Cout);
-  else return S2S_ERR_DTYPE;
-  S2S_LAUNCH_CHECK();
-  return S2S_OK;
+  return s2s_internal_stem_fwd(dtype, x_nchw, w_oihw, bias, y, ldy, stat_part, B, H, W, Cin, Cout,
+                               (hipStream_t)stream);
 }
 
 extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {

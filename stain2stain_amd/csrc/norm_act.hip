@@ -22,6 +22,35 @@ namespace {
 constexpr int RED_ROWS = 8;  // pixel groups per workgroup in the reduction kernels (256 = 32 x 8)
 
 // ---------------------------------------------------------------------------------------------
+// row pre-reduction: part[nrows][ncols] -> its own first R rows (row r <- sum of rows r, r+R, r+2R, ...).
+// The finalize kernels below are one workgroup per 32 channels, which leaves a 4096-row partial buffer to
+// two or four CUs; this spreads the bulk of the sum over (ncols/32) x R workgroups first.  In place and
+// race free: row r is read and written by workgroup r only.
+// ---------------------------------------------------------------------------------------------
+constexpr int PRE_R = 16;
+__global__ __launch_bounds__(1024) void prereduce_rows_kernel(float* __restrict__ part, int nrows, int ncols) {
+  __shared__ double s1[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, r = blockIdx.y;
+  double a = 0.0;
+  if (c < ncols)
+    for (int i = r + PRE_R * rg; i < nrows; i += PRE_R * 32) a += (double)part[(long)i * ncols + c];
+  s1[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && c < ncols) {
+    for (int k = 1; k < 32; ++k) a += s1[k][cl];
+    part[(long)r * ncols + c] = (float)a;
+  }
+}
+
+// returns the row count the finalize kernel should read
+inline int prereduce(float* part, int nrows, int ncols, hipStream_t s) {
+  if (nrows <= 4 * PRE_R) return nrows;
+  hipLaunchKernelGGL(prereduce_rows_kernel, dim3(cdiv(ncols, 32), PRE_R), dim3(1024), 0, s, part, nrows, ncols);
+  return PRE_R;
+}
+
+// ---------------------------------------------------------------------------------------------
 // statistics finalize
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
@@ -478,6 +507,7 @@ extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, c
                                void* stream) {
   if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift) return S2S_ERR_NULL;
   if (nblk <= 0 || C <= 0 || count <= 0) return S2S_ERR_SHAPE;
+  nblk = prereduce(const_cast<float*>(part), nblk, 2 * C, (hipStream_t)stream);   // part is scratch: reduced in place
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, C,
                      (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
                      invstd, scale, shift);
@@ -564,8 +594,8 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
     hipLaunchKernelGGL(bn_relu_bwd_reduce_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,             \
                        scale, shift, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
   }                                                                                                                \
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, nb, C, count, dgamma,      \
-                     dbeta, accumulate, c1, c2);                                                                   \
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, prereduce(part, nb, 2 * C, s), \
+                     C, count, dgamma, dbeta, accumulate, c1, c2);                                                                   \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
                        ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
@@ -580,8 +610,8 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   else return S2S_ERR_DTYPE;
 #undef S2S_BN_BWD
   if (dbias_conv)
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part2, nb, C, dbias_conv,
-                       accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part2, prereduce(part2, nb, C, s),
+                       C, dbias_conv, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

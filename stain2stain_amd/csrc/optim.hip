@@ -56,6 +56,42 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
+// All conv layers in one launch, LDS-tiled so that both the OIHW reads and the two packed writes are coalesced.
+// desc[l] = {w_oihw ptr, w_fwd ptr, w_dgrad ptr, Cout, Cin, first tile} (6 x int64 per layer); one workgroup
+// repacks a 32(co) x 32(ci) x 9(tap) tile: rows of 32*9 contiguous floats in, 2-KB [32][32] bf16/fp32 blocks out.
+struct PackDesc {
+  long w, wf, wd, cout, cin, start;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_batched_kernel(const PackDesc* __restrict__ desc, int nlayers) {
+  __shared__ float tile[32][289];
+  int l = 0;
+  while (l + 1 < nlayers && desc[l + 1].start <= (long)blockIdx.x) ++l;
+  const PackDesc d = desc[l];
+  const float* __restrict__ w = reinterpret_cast<const float*>(d.w);
+  T* __restrict__ wf = reinterpret_cast<T*>(d.wf);
+  T* __restrict__ wd = reinterpret_cast<T*>(d.wd);
+  const int Cout = (int)d.cout, Cin = (int)d.cin;
+  const int nci = (Cin + 31) / 32;
+  const int t = blockIdx.x - (int)d.start;
+  const int co0 = (t / nci) * 32, ci0 = (t % nci) * 32;
+  for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+    const int co = idx / 288, j = idx - co * 288;
+    const int ci = ci0 + j / 9;
+    tile[co][j] = (co0 + co < Cout && ci < Cin) ? w[((long)(co0 + co) * Cin + ci0) * 9 + j] : 0.f;
+  }
+  __syncthreads();
+  const int c = ci0 / 32, cp = co0 / 32;
+  for (int idx = threadIdx.x; idx < 9 * 1024; idx += 256) {
+    const int k = idx & 31, row = (idx >> 5) & 31, tap = idx >> 10;
+    // forward: Wf[c][tap][co0+row][k = ci]
+    if (co0 + row < Cout) wf[(((long)c * 9 + tap) * Cout + co0 + row) * 32 + k] = from_f32<T>(tile[row][k * 9 + tap]);
+    // data gradient: Wd[cp][tap][ci0+row][k = co] = W[co][ci][8 - tap]
+    if (wd && ci0 + row < Cin) wd[(((long)cp * 9 + tap) * Cin + ci0 + row) * 32 + k] = from_f32<T>(tile[k][row * 9 + (8 - tap)]);
+  }
+}
+
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int ldy, int B, int C, int HW) {
   const int cp = C >> 3;
@@ -128,6 +164,23 @@ extern "C" int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, voi
   else if (dtype == S2S_F32)
     hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, w_oihw, (float*)w_fwd,
                        (float*)w_dgrad, Cout, Cin);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// desc: device array of nlayers x 6 int64 {w_oihw, w_fwd, w_dgrad, Cout, Cin, start}; `start` = running sum of
+// ceil(Cout/32)*ceil(Cin/32) (32x32 tiles) over the preceding layers, total = that sum over all layers.
+extern "C" int s2s_pack_conv3x3_batched(int dtype, const void* desc, int nlayers, long total, void* stream) {
+  if (!desc) return S2S_ERR_NULL;
+  if (nlayers <= 0 || nlayers > 256 || total <= 0 || total > 0x7fffffffL) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_batched_kernel<bf16_t>, dim3((unsigned)total), dim3(256), 0, s,
+                       (const PackDesc*)desc, nlayers);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pack_conv3x3_batched_kernel<float>, dim3((unsigned)total), dim3(256), 0, s,
+                       (const PackDesc*)desc, nlayers);
   else return S2S_ERR_DTYPE;
   S2S_LAUNCH_CHECK();
   return S2S_OK;

@@ -63,6 +63,23 @@ class ConvBN:
     def invalidate(self) -> None:
         self._pack_key.clear()
 
+    def ensure_buffers(self, dtype: torch.dtype):
+        """Allocate (once) the packed buffers without filling them; returns (wf, wd)."""
+        old = self._pack.get(dtype)
+        w = self.conv.weight
+        if old is None or old[0].device != w.device:
+            L = ops._L()
+            wf = torch.empty((L.s2s_pack_conv3x3_fwd_elems(self.cout, self.cin),), dtype=dtype, device=w.device)
+            wd = torch.empty((L.s2s_pack_conv3x3_dgrad_elems(self.cout, self.cin),), dtype=dtype, device=w.device)
+            self._pack[dtype] = (wf, wd)
+            self._pack_key.pop(dtype, None)
+        return self._pack[dtype]
+
+    def mark_packed(self, dtype: torch.dtype) -> None:
+        """The packed copies were just refreshed externally (batched pack) from the current master weight."""
+        w = self.conv.weight
+        self._pack_key[dtype] = (w.data_ptr(), w._version, w.device)
+
 
 @dataclass
 class LayerCtx:

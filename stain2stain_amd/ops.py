@@ -436,6 +436,14 @@ def pack_conv3x3(w_oihw: torch.Tensor, dtype: torch.dtype, want_dgrad: bool = Tr
     return wf, wd
 
 
+@_timed("pack_conv3x3")
+def pack_conv3x3_batched(desc: torch.Tensor, total: int, dtype: torch.dtype) -> None:
+    """desc: int64 [nlayers, 6] device tensor {w ptr, wf ptr, wd ptr, Cout, Cin, first tile}; total = tiles."""
+    code = BF16 if dtype == torch.bfloat16 else F32
+    _native.check(_L().s2s_pack_conv3x3_batched(code, desc.data_ptr(), desc.shape[0], int(total), _stream()),
+                  "pack_conv3x3_batched")
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, C, H, W = x.shape
     if out is None:

@@ -87,9 +87,17 @@ class CFMTrainer:
         self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group)
         broadcast_from_rank0([self.flat_p] + [b for b in net.buffers()], process_group)
         self._blocks = list(net.encoder._blocks) + list(net.flow_decoder.up_blocks)
-        for pair in self._blocks:
-            for cb in pair:
-                cb.invalidate()
+        # one launch re-packs every MFMA conv's weights (all but the stem, which reads the fp32 master directly)
+        self._dtype = net.encoder.compute_dtype
+        self._packed = [cb for pair in self._blocks for cb in pair if cb is not net.encoder._blocks[0][0]]
+        rows, start = [], 0
+        for cb in self._packed:
+            wf, wd = cb.ensure_buffers(self._dtype)
+            rows.append([cb.conv.weight.data_ptr(), wf.data_ptr(), wd.data_ptr(), cb.cout, cb.cin, start])
+            start += ((cb.cout + 31) // 32) * ((cb.cin + 31) // 32)
+        self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._pack_total = start
+        self._repack()
 
     # ------------------------------------------------------------------------------------------
     def forward_backward(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None):
@@ -122,9 +130,12 @@ class CFMTrainer:
         self.step_count += 1
         ops.adam_step_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas[0],
                        self.betas[1], self.eps, self.wd, self.bucketer.grad_scale)
-        for pair in self._blocks:   # master weights changed behind torch's version counter
-            for cb in pair:
-                cb.invalidate()
+        self._repack()              # master weights changed behind torch's version counter
+
+    def _repack(self) -> None:
+        ops.pack_conv3x3_batched(self._pack_desc, self._pack_total, self._dtype)
+        for cb in self._packed:
+            cb.mark_packed(self._dtype)
 
     def step(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One training step on this rank's shard of the global batch; returns the (rank-mean) loss."""
