@@ -75,6 +75,14 @@ int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void* x, int ldx
                          float* part, float* dw, float* dbias, int accumulate, int B, int H, int W, int C, int Cout,
                          void* stream);
 
+/* head + loss + their backward in one pass over the last activation (training step only):
+ * v = W a + b (optional output), loss = mean((v-u)^2), dx = W^T dv, dW/db with dv = 2 (v-u) grad_scale / count
+ * (task_decoders.py:132 + conditional_flow_matching.py:72).  part: float[blocks][Cout][C+1]; lpart: double[blocks] */
+int s2s_head_loss_blocks(int B, int H, int W);
+int s2s_head_loss_fused(int dtype, const void* x, int ldx, const float* w, const float* bias, const float* u_nchw,
+                        float* v_nchw, void* dx, int lddx, float grad_scale, float* part, double* lpart, float* dw,
+                        float* dbias, float* loss, int accumulate, int B, int H, int W, int C, int Cout, void* stream);
+
 /* ---- BatchNorm2d + ReLU (+ MaxPool2d(2)) (norm_act.hip) -------------------------------------------
  * nn.BatchNorm2d(eps 1e-5, momentum 0.1) -> nn.ReLU of DoubleConv (shared_encoder.py:16-20) and the
  * nn.MaxPool2d(2) of the following Down block (shared_encoder.py:33). */

@@ -366,6 +366,129 @@ __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* par
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// head + loss fused (training step): one pass over the last activation computes
+//   v = W a + b,  loss += (v-u)^2,  dv = coef (v-u),  da = W^T dv,  dW += dv a^T,  db += dv
+// i.e. FlowMatchingDecoder.outc (task_decoders.py:132) + mean((vt-ut)**2) (conditional_flow_matching.py:72)
+// + their backward, reading the 64-channel activation once instead of three times.
+// part[gridDim.x][Cout][C+1] (dW | db), lpart[gridDim.x] (double, sum of squares).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_fused_kernel(const T* __restrict__ x, int ldx,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ u, float* __restrict__ v_out,
+                                                              T* __restrict__ dx, int lddx, float coef,
+                                                              float* __restrict__ part, double* __restrict__ lpart,
+                                                              long npix, int HW, int C, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);                 // [Cout][C]
+  float* gl = wl + HEAD_MAX_COUT * C;                          // [256][HEAD_MAX_COUT] dv
+  bf16_t* al = reinterpret_cast<bf16_t*>(gl + 256 * HEAD_MAX_COUT);   // [256][C+8] activation tile (bf16 is enough for dW)
+  __shared__ double lred[256];
+  const int AS = C + 8;
+  for (int i = threadIdx.x; i < Cout * C; i += 256) wl[i] = w[i];
+  const int nout = Cout * (C + 1);
+  float acc[4];                                                // outputs tid, tid+256, ... (nout <= 1024)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+  double lsum = 0.0;
+  __syncthreads();
+  for (long p0 = (long)blockIdx.x * 256; p0 < npix; p0 += (long)gridDim.x * 256) {
+    const long p = p0 + threadIdx.x;
+    const bool ok = p < npix;
+    float g[HEAD_MAX_COUT];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_COUT; ++o) g[o] = 0.f;
+    if (ok) {
+      float vv[HEAD_MAX_COUT];
+#pragma unroll
+      for (int o = 0; o < HEAD_MAX_COUT; ++o) vv[o] = 0.f;
+      for (int c8 = 0; c8 < C; c8 += 8) {
+        const f32x8 a = load8(x + p * ldx + c8);
+        bf16x8 ab;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ab[k] = (bf16_t)a.v[k];
+        *reinterpret_cast<bf16x8*>(al + threadIdx.x * AS + c8) = ab;
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_COUT; ++o)
+          if (o < Cout)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vv[o] = fmaf(a.v[k], wl[o * C + c8 + k], vv[o]);
+      }
+      const long n = p / HW, q = p - n * HW;
+#pragma unroll
+      for (int o = 0; o < HEAD_MAX_COUT; ++o)
+        if (o < Cout) {
+          const float vo = vv[o] + (bias ? bias[o] : 0.f);
+          const long idx = (n * Cout + o) * HW + q;
+          if (v_out) v_out[idx] = vo;
+          const float d = vo - u[idx];
+          lsum += (double)(d * d);
+          g[o] = coef * d;
+        }
+      for (int c8 = 0; c8 < C; c8 += 8) {
+        f32x8 da;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float s = 0.f;
+#pragma unroll
+          for (int o = 0; o < HEAD_MAX_COUT; ++o)
+            if (o < Cout) s = fmaf(g[o], wl[o * C + c8 + k], s);
+          da.v[k] = s;
+        }
+        store8(dx + p * lddx + c8, da);
+      }
+    } else {
+      for (int c8 = 0; c8 < C; c8 += 8) {
+        bf16x8 z;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = (bf16_t)0.f;
+        *reinterpret_cast<bf16x8*>(al + threadIdx.x * AS + c8) = z;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_COUT; ++o) gl[threadIdx.x * HEAD_MAX_COUT + o] = g[o];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = threadIdx.x + i * 256;
+      if (id < nout) {
+        const int o = id / (C + 1), c = id - o * (C + 1);
+        float a = acc[i];
+        if (c < C) for (int pp = 0; pp < 256; ++pp) a = fmaf(gl[pp * HEAD_MAX_COUT + o], (float)al[pp * AS + c], a);
+        else for (int pp = 0; pp < 256; ++pp) a += gl[pp * HEAD_MAX_COUT + o];
+        acc[i] = a;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = threadIdx.x + i * 256;
+    if (id < nout) part[(long)blockIdx.x * nout + id] = acc[i];
+  }
+  lred[threadIdx.x] = lsum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) lred[threadIdx.x] += lred[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lpart[blockIdx.x] = lred[0];
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* part, int n, double inv_count, float* loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
+}
+
 }  // namespace
 
 // MFMA stem forward lives next to the shared epilogue in conv3x3_mfma.hip
@@ -475,6 +598,42 @@ extern "C" int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void*
 #undef S2S_HEAD_BWD
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
                      dw, dbias, accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_head_loss_blocks(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
+  const long nb = ((long)B * H * W + 255) / 256;
+  return (int)(nb < 1024 ? nb : 1024);
+}
+
+// part: float[blocks][Cout][C+1]; lpart: double[blocks]; v_out (optional) NCHW fp32; dv scale = 2*grad_scale/count
+extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const float* w, const float* bias,
+                                   const float* u_nchw, float* v_nchw, void* dx, int lddx, float grad_scale,
+                                   float* part, double* lpart, float* dw, float* dbias, float* loss, int accumulate,
+                                   int B, int H, int W, int C, int Cout, void* stream) {
+  if (!x || !w || !u_nchw || !dx || !part || !lpart || !dw || !loss) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) || Cout <= 0 || Cout > HEAD_MAX_COUT)
+    return S2S_ERR_SHAPE;
+  if (Cout * (C + 1) > 1024) return S2S_ERR_SHAPE;
+  const long npix = (long)B * H * W;
+  const double count = (double)npix * Cout;
+  const int nb = s2s_head_loss_blocks(B, H, W);
+  const int lds = (HEAD_MAX_COUT * C + 256 * HEAD_MAX_COUT) * 4 + 256 * (C + 8) * 2;
+  if (lds > 60 * 1024) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const float coef = (float)(2.0 * (double)grad_scale / count);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(head_loss_fused_kernel<bf16_t>, dim3(nb), dim3(256), lds, s, (const bf16_t*)x, ldx, w, bias,
+                       u_nchw, v_nchw, (bf16_t*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(head_loss_fused_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)x, ldx, w, bias,
+                       u_nchw, v_nchw, (float*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
+  else return S2S_ERR_DTYPE;
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
+                     dw, dbias, accumulate);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, lpart, nb, 1.0 / count, loss);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -208,8 +208,9 @@ def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeat
 # decoder
 # ------------------------------------------------------------------------------------------------
 def decoder_forward(dec, bottleneck: torch.Tensor, skips: Sequence[torch.Tensor], t_emb: torch.Tensor,
-                    dtype: torch.dtype, training: bool) -> DecCtx:
-    """dec: FlowMatchingDecoder container (time_mlp, time_proj, up_blocks, outc)."""
+                    dtype: torch.dtype, training: bool, with_head: bool = True) -> DecCtx:
+    """dec: FlowMatchingDecoder container (time_mlp, time_proj, up_blocks, outc).  with_head=False stops at the
+    last activation (ctx.lows[-1]); the fused head+loss kernel of the training step takes it from there."""
     ctx = DecCtx(dtype, t_emb)
     l0, l2 = dec.time_mlp[0], dec.time_mlp[2]
     ctx.h1 = ops.linear_fwd(t_emb, l0.weight.detach(), l0.bias.detach())
@@ -226,16 +227,22 @@ def decoder_forward(dec, bottleneck: torch.Tensor, skips: Sequence[torch.Tensor]
         ctx.lows.append(x); ctx.ups.append(up); ctx.skips.append(skip); ctx.layers.append((lc1, lc2))
         x = a2
     ctx.lows.append(x)  # head input
+    if not with_head:
+        return ctx
     ctx.v = ops.head_fwd(x, dec.outc.weight.detach(), dec.outc.bias.detach() if dec.outc.bias is not None else None)
     return ctx
 
 
-def decoder_backward(dec, ctx: DecCtx, dv: torch.Tensor, grads: Dict[str, torch.Tensor], accumulate: bool = False,
-                     need_dt_emb: bool = False, on_group_done=None):
+def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[str, torch.Tensor],
+                     accumulate: bool = False, need_dt_emb: bool = False, on_group_done=None,
+                     g_head: Optional[torch.Tensor] = None):
     """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype.
     ``on_group_done(k)``: k = 0 after the head, 1.. after each Up block (last block first), then the time path."""
-    g = ops.head_bwd(dv, ctx.lows[-1], dec.outc.weight.detach(), _g(grads, "outc.weight"),
-                     _g(grads, "outc.bias") if dec.outc.bias is not None else None, accumulate)
+    if g_head is not None:      # head gradients already produced by the fused head+loss kernel
+        g = g_head
+    else:
+        g = ops.head_bwd(dv, ctx.lows[-1], dec.outc.weight.detach(), _g(grads, "outc.weight"),
+                         _g(grads, "outc.bias") if dec.outc.bias is not None else None, accumulate)
     if on_group_done is not None:
         on_group_done(0)
     nup = len(ctx.layers)

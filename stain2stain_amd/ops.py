@@ -231,6 +231,28 @@ def head_bwd(dy_nchw: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.
     return dx
 
 
+@_timed("head_loss_fused")
+def head_loss_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], u_nchw: torch.Tensor,
+                    dw: torch.Tensor, dbias: Optional[torch.Tensor], want_v: bool = False, grad_scale: float = 1.0,
+                    accumulate: bool = False):
+    """Returns (loss, dx, v or None): head conv + MSE loss + both backward passes in one sweep."""
+    B, H, W, C = x.shape
+    cout = w.shape[0]
+    px, ldx = _nhwc(x)
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    v = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device) if want_v else None
+    nb = _L().s2s_head_loss_blocks(B, H, W)
+    part = torch.empty((nb, cout, C + 1), dtype=torch.float32, device=x.device)
+    lpart = torch.empty((nb,), dtype=torch.float64, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_head_loss_fused(_dt(x), px, ldx, _f32(w.reshape(cout, C)), _f32(bias), _f32(u_nchw), _f32(v),
+                                  dx.data_ptr(), C, float(grad_scale), _f32(part), lpart.data_ptr(),
+                                  _f32(dw.reshape(cout, C)), _f32(dbias), loss.data_ptr(), int(accumulate), B, H, W, C,
+                                  cout, _stream())
+    _native.check(rc, "head_loss_fused")
+    return loss, dx, v
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU (+ pool)
 # ------------------------------------------------------------------------------------------------

@@ -100,8 +100,10 @@ class CFMTrainer:
         self._repack()
 
     # ------------------------------------------------------------------------------------------
-    def forward_backward(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None):
-        """Gradients of the local batch into the flat buffer (+ async all-reduce).  Returns (loss, v)."""
+    def forward_backward(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None,
+                         want_v: bool = True):
+        """Gradients of the local batch into the flat buffer (+ async all-reduce).  Returns (loss, v); the
+        velocity field is only materialised when ``want_v`` (tests) -- the training step does not need it."""
         net = self.net
         enc, dec = net.encoder, net.flow_decoder
         dt = enc.compute_dtype
@@ -113,11 +115,16 @@ class CFMTrainer:
         ectx = engine.encoder_forward(enc._blocks, xt, dt, True)
         temb = ops.time_embedding(t, net.time_embedding.dim)
         feats = ectx.feats
-        dctx = engine.decoder_forward(dec, feats[-1], feats[:-1][::-1], temb, dt, True)
-        loss, dv = ops.mse_loss(dctx.v, ut, want_grad=True)
+        dctx = engine.decoder_forward(dec, feats[-1], feats[:-1][::-1], temb, dt, True, with_head=False)
+        # head conv + loss + their backward in one sweep over the last activation
+        loss, g_head, v = ops.head_loss_fused(dctx.lows[-1], dec.outc.weight.detach(),
+                                              dec.outc.bias.detach() if dec.outc.bias is not None else None, ut,
+                                              self.grads_dec["outc.weight"], self.grads_dec.get("outc.bias"),
+                                              want_v=want_v)
+        dctx.v = v
         self.bucketer.start_step()
         nd = self.n_dec_groups
-        dbott, dskips, _ = engine.decoder_backward(dec, dctx, dv, self.grads_dec,
+        dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
                                                    on_group_done=lambda k: self.bucketer.mark_ready(k))
         L = len(feats) - 1
         dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
@@ -139,7 +146,7 @@ class CFMTrainer:
 
     def step(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One training step on this rank's shard of the global batch; returns the (rank-mean) loss."""
-        loss, _ = self.forward_backward(x0, x1, t)
+        loss, _ = self.forward_backward(x0, x1, t, want_v=False)
         work = all_reduce_mean_scalar(loss, self.pg) if self.sync_loss else None
         self.optimizer_step()
         if work is not None:

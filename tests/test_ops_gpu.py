@@ -289,3 +289,26 @@ def test_layout_roundtrip_and_error_status():
         assert relerr(ops.nhwc_to_nchw(y).cpu(), rnd(x, dt)) == 0.0
     with pytest.raises(RuntimeError):   # channel count not a multiple of 8 -> negative status -> exception
         ops.nchw_to_nhwc(torch.rand(1, 12, 4, 4, device=DEV), torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_loss_fused_matches_separate_ops(dtype):
+    """Fused head conv + MSE + backward (training step) against autograd on the CPU."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = 2, 16, 19, 23
+    a = rnd(torch.rand(B, C, H, W, generator=g) * 2 - 1, dtype).requires_grad_(True)
+    w = ((torch.rand(3, C, 1, 1, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    b = (torch.rand(3, generator=g) - 0.5).requires_grad_(True)
+    u = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    v_ref = F.conv2d(a, w, b)
+    loss_ref = ((v_ref - u) ** 2).mean()
+    loss_ref.backward()
+    dw = torch.empty(3, C, 1, 1, device=DEV); db = torch.empty(3, device=DEV)
+    loss, dx, v = ops.head_loss_fused(nhwc(a.detach(), dtype), w.detach().to(DEV), b.detach().to(DEV), u.to(DEV), dw, db,
+                                      want_v=True)
+    assert relerr(v.cpu(), v_ref) < 1e-5
+    assert relerr(loss.cpu(), loss_ref) < 1e-5
+    assert relerr(nchw(dx), a.grad) < tol_act(dtype)
+    assert relerr(dw.cpu(), w.grad) < (5e-3 if dtype == torch.bfloat16 else 5e-3)   # dW uses a bf16 copy of the activation
+    assert relerr(db.cpu(), b.grad) < 1e-4
