@@ -125,6 +125,16 @@ def main() -> None:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += work
         dom = "conv3x3_mfma"          # forward + data-gradient implicit-GEMM kernel
+        # HBM bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same command, gfx950 correction applied); the committed summary is read back here
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_current.json")
+        if os.path.exists(tpath) and args.batch == BATCH_PER_GPU and args.precision == "bf16":
+            try:
+                tj = json.load(open(tpath))
+                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in tj.items() if k.startswith("conv3x3_mfma"))
+            except Exception:  # noqa: BLE001
+                traffic = None
         n_l, t_l, f_l = agg[dom]
         achieved = f_l / t_l / 1e12
         kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / args.steps, 4),
@@ -144,7 +154,8 @@ def main() -> None:
                        "final_loss": round(float(loss), 6)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fwd + dgrad launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/hbm_traffic_current.json)",
                          "launches_per_step": n_l // args.steps,
                          "avg_launch_ms": round(t_l * 1e3 / n_l, 4),
                          "algorithmic_gflop_per_launch": round(f_l / n_l / 1e9, 3)},
