@@ -52,7 +52,7 @@ int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1,
 /* ---- 3x3 convolution weight gradient (conv3x3_wgrad_mfma.hip) -----------------------------------
  * autograd's conv2d weight gradient for the same layers.  part: float[splits][9][Cout][c0+c1] scratch;
  * grad_oihw: float[Cout][c0+c1][3][3], overwritten or accumulated. */
-int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout);
 int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
                            const void* x1, int ld1, int c1, float* part, float* grad_oihw, int accumulate,
                            int B, int H, int W, void* stream);

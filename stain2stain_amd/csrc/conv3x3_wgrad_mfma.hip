@@ -240,15 +240,20 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int TH, int TW>
+// NT = 9: a workgroup accumulates all nine taps (one dY fragment feeds nine MFMAs).
+// NT = 3: the three kh rows go to three workgroups (blockIdx.z = split*3 + kh) that each accumulate the three kw
+//         taps of their row and stage only the TH halo rows they need.  Three times the workgroups for the same
+//         number of pixel splits, i.e. a third of the partial-slab traffic for the same machine fill -- used for
+//         the layers with few (co,ci) tiles, where the slabs, not the MFMAs, set the time.
+template <int TH, int TW, int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
   using T = bf16_t;
   constexpr int NPX = TH * TW;                             // 128
-  constexpr int HW_ = TW + 2, HALO = (TH + 2) * HW_;       // 180
-  constexpr int XROWS = (HALO + 15) / 16 * 16;             // 192 (padded to whole DMA groups)
+  constexpr int HW_ = TW + 2, HR = (NT == 9) ? TH + 2 : TH, HALO = HR * HW_;
+  constexpr int XROWS = (HALO + 31) / 32 * 32;             // 192 / 160 (whole DMA groups, 4 waves x 2 halves)
   constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
   constexpr int DYG = 2 * NPX / 16 / 4;                    // dY DMA instr per wave (4)
-  constexpr int XG = 2 * XROWS / 16 / 4;                   // halo DMA instr per wave (6)
+  constexpr int XG = 2 * XROWS / 16 / 4;                   // halo DMA instr per wave (6 / 5)
   constexpr int BUF = DY_BYTES + X_BYTES;
   constexpr int KSTEPS = NPX / 16;
   static_assert((2 * NPX / 16) % 4 == 0 && (2 * XROWS / 16) % 4 == 0, "DMA groups split evenly over 4 waves");
@@ -264,13 +269,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
   const int cin = a.c0 + a.c1;
   const int drow = lane >> 2, dslot = lane & 3;
+  const int kh0 = (NT == 9) ? 0 : (int)(blockIdx.z % 3);
+  const int zsplit = (NT == 9) ? (int)blockIdx.z : (int)(blockIdx.z / 3);
 
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
@@ -293,10 +300,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
     }
 #pragma unroll
     for (int j = 0; j < XG; ++j) {
-      const int grp = wave + 4 * j;                  // 0..23: half = grp / 12
+      const int grp = wave + 4 * j;
       const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
       const int hy = px / HW_, hx = px - hy * HW_;
-      const int gy = y0 - 1 + hy, gx = xs - 1 + hx, ci = ci0 + half * 32 + dslot * 8;
+      const int gy = y0 - 1 + kh0 + hy, gx = xs - 1 + hx, ci = ci0 + half * 32 + dslot * 8;
       const void* src = g_wgrad_zero_page;
       if (px < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
         const long pix = (long)(img * a.H + gy) * a.W + gx;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
     }
   };
 
-  int tile = blockIdx.z;
+  int tile = zsplit;
   int buf = 0;
   if (tile < a.ntiles) dma_tile(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,10 +329,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
       const int py = m0 / TW, px = m0 - py * TW;
       const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int hoff = ((py + tap / 3) * HW_ + px + tap % 3) * 64;
+      for (int t = 0; t < NT; ++t) {
+        const int hoff = ((py + t / 3) * HW_ + px + t % 3) * 64;
         const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
       }
     }
     // every MFMA (hence every LDS read of this buffer) is issued before the barrier: the next iteration's DMA
@@ -339,12 +346,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   const int r = lane & 31, h = lane >> 5;
   const int ci = ci0 + wci * 32 + r;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int t = 0; t < NT; ++t) {
+    const int tap = kh0 * 3 + t;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
       if (co < a.Cout && ci < cin)
-        a.part[(((long)blockIdx.z * 9 + tap) * a.Cout + co) * cin + ci] = acc[tap][j];
+        a.part[(((long)zsplit * 9 + tap) * a.Cout + co) * cin + ci] = acc[t][j];
     }
   }
 }
@@ -399,25 +407,33 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   return S2S_OK;
 }
 
-template <int TH, int TW>
+template <int TH, int TW, int NT>
 int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
-  constexpr int XROWS = ((TH + 2) * (TW + 2) + 15) / 16 * 16;
+  constexpr int XROWS = (((NT == 9) ? TH + 2 : TH) * (TW + 2) + 31) / 32 * 32;
   constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   a.ntiles = a.B * a.tilesY * a.tilesX;
   if (a.S > a.ntiles) return S2S_ERR_SHAPE;
-  auto kern = conv3x3_wgrad_dma_kernel<TH, TW>;
+  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return S2S_ERR_LAUNCH;
     attr_done = true;
   }
-  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S);
+  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * (NT == 9 ? 1 : 3));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+// layers with at most this many 64x64 (co,ci) tiles split the kh rows over workgroups (bf16 DMA kernel)
+inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
+  static const int mode = [] { const char* e = getenv("S2S_WGRAD_KH"); return e ? atoi(e) : -1; }();
+  if (dtype != S2S_BF16) return 0;
+  if (mode >= 0) return mode;
+  return cdiv(Cin, 64) * cdiv(Cout, 64) <= 2;   // measured: pays for 64->64 and 64<->128 at batch 16, loses beyond
 }
 
 // one pixel tile = 8 rows x 16 columns (halo 10 x 18); this shape keeps the staging prefetch small
@@ -428,10 +444,10 @@ int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
 
 // Split count the kernel will use for this problem; the caller sizes `part` as
 // [splits][9][Cout][Cin] floats.
-extern "C" int s2s_conv3x3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = wgrad_ntiles(B, H, W);
-  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (wgrad_kh_split(dtype, Cin, Cout) ? 3 : 1);
   static const int target = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
   // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
   // slab, so the few-channel layers (mn = 1..2) stop at 320 splits
@@ -453,11 +469,13 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
   a.B = B; a.H = H; a.W = W;
-  a.S = s2s_conv3x3_wgrad_splits(B, H, W, c0 + c1, Cout);
+  a.S = s2s_conv3x3_wgrad_splits(dtype, B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   static const int use_dma = [] { const char* e = getenv("S2S_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype == S2S_BF16) rc = use_dma ? launch_wgrad_dma<8, 16>(a, s) : launch_wgrad<bf16_t, 8, 16>(a, s);
+  if (dtype == S2S_BF16 && use_dma)
+    rc = wgrad_kh_split(dtype, c0 + c1, Cout) ? launch_wgrad_dma<8, 16, 3>(a, s) : launch_wgrad_dma<8, 16, 9>(a, s);
+  else if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
   else if (dtype == S2S_F32) rc = launch_wgrad<float, 8, 16>(a, s);
   else return S2S_ERR_DTYPE;
   if (rc != S2S_OK) return rc;

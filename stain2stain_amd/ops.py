@@ -166,7 +166,7 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
         c1 = x1.shape[3]
     if tuple(grad_oihw.shape) != (cout, c0 + c1, 3, 3):
         raise RuntimeError("stain2stain_amd: conv3x3_wgrad gradient buffer has the wrong shape")
-    s = _L().s2s_conv3x3_wgrad_splits(B, H, W, c0 + c1, cout)
+    s = _L().s2s_conv3x3_wgrad_splits(dt, B, H, W, c0 + c1, cout)
     part = torch.empty((s, 9, cout, c0 + c1), dtype=torch.float32, device=dy.device)
     rc = _L().s2s_conv3x3_wgrad_nhwc(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
                                      int(accumulate), B, H, W, _stream())

@@ -29,8 +29,8 @@ def test_host_side_validation_returns_status_codes_without_a_gpu():
     assert lib.s2s_conv3x3_stat_blocks(0, 16, 256, 256, 64) == 16 * 32 * 8
     assert lib.s2s_conv3x3_stat_blocks(1, 16, 256, 256, 64) == 16 * 64 * 8
     assert lib.s2s_conv3x3_stat_blocks(7, 1, 8, 8, 8) == -3
-    assert lib.s2s_conv3x3_wgrad_splits(16, 256, 256, 64, 64) >= 1
-    assert lib.s2s_conv3x3_wgrad_splits(0, 1, 1, 8, 8) == -1
+    assert lib.s2s_conv3x3_wgrad_splits(0, 16, 256, 256, 64, 64) >= 1
+    assert lib.s2s_conv3x3_wgrad_splits(0, 0, 1, 1, 8, 8) == -1
     assert lib.s2s_pack_conv3x3_fwd_elems(64, 48) == 9 * 2 * 64 * 32
     assert lib.s2s_pack_conv3x3_dgrad_elems(64, 48) == 9 * 2 * 48 * 32
     assert lib.s2s_bn_bwd_blocks(2, 0, 4, 8) == -1
