@@ -357,30 +357,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   }
 }
 
-// grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci]; one thread per (co, ci, tap) with ci fastest across lanes
-// for the reads; the 9 taps of one (co,ci) are gathered through LDS so the OIHW store is contiguous.
+// grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci].  A workgroup owns 64 consecutive (co,ci) pairs; its four
+// waves take every fourth split (reads stay coalesced along ci), the sums meet in LDS and leave as 64*9
+// contiguous floats of the OIHW gradient.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
                                     int Cin, int accumulate) {
-  __shared__ float tile[9][257];
+  __shared__ float tile[4][9][65];
   const long n = (long)Cout * Cin;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (co, ci)
+  const int il = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + il;  // (co, ci)
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
   if (i < n) {
-    for (int z = 0; z < S; ++z)
+    for (int z = zg; z < S; z += 4)
 #pragma unroll
       for (int t = 0; t < 9; ++t) s[t] += part[((long)z * 9 + t) * n + i];
   }
 #pragma unroll
-  for (int t = 0; t < 9; ++t) tile[t][threadIdx.x] = s[t];
+  for (int t = 0; t < 9; ++t) tile[zg][t][il] = s[t];
   __syncthreads();
-  // 256 (co,ci) pairs x 9 taps = 2304 contiguous floats of the OIHW gradient
-  const long base = (long)blockIdx.x * 256 * 9;
-  for (int k = threadIdx.x; k < 2304; k += 256) {
+  const long base = (long)blockIdx.x * 64 * 9;
+  for (int k = threadIdx.x; k < 576; k += 256) {
     const long o = base + k;
     if (o < n * 9) {
-      const float v = tile[k % 9][k / 9];
+      const int t = k % 9, j = k / 9;
+      const float v = tile[0][t][j] + tile[1][t][j] + tile[2][t][j] + tile[3][t][j];
       grad[o] = accumulate ? grad[o] + v : v;
     }
   }
@@ -480,7 +482,7 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   else return S2S_ERR_DTYPE;
   if (rc != S2S_OK) return rc;
   const long n = (long)Cout * (c0 + c1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad_oihw, a.S,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, grad_oihw, a.S,
                      Cout, c0 + c1, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
