@@ -29,8 +29,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
 for (H, c0, c1, cout) in FWD:
     cin = c0 + c1
-    x = (torch.rand(B, H, H, cin, device=dev) * 2 - 1).to(dt)
-    w = (torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1
+    x = ((torch.rand(B, H, H, cin, device=dev) * 2 - 1) * float(os.environ.get("ZERO", "1") != "0")).to(dt)
+    w = (torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1 * float(os.environ.get("ZERO", "1") != "0")
     wf, wd = ops.pack_conv3x3(w, dt)
     dy = (torch.rand(B, H, H, cout, device=dev) * 2 - 1).to(dt)
     bias = torch.zeros(cout, device=dev)
