@@ -147,6 +147,13 @@ int s2s_nchw_to_nhwc(int dtype, const float* x_nchw, void* y, int ldy, int B, in
 int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accumulate, int B, int C, int H, int W,
                      void* stream);
 
+/* ---- paired input pipeline (input_pipeline.hip) -- SURVEY section 8 row f1 --------------------------
+ * PairedDataset.__getitem__ transform chain (src/data/paired_data_module.py:170-199): shared crop + h/v flips,
+ * to_tensor, Normalize(0.5, 0.5).  src/tgt: uint8 [B][Hs][Ws][3]; params: int32 [B][4] {top, left, hflip, vflip};
+ * out: float [B][3][S][S]. */
+int s2s_paired_crop_flip_normalize(const void* src_u8, const void* tgt_u8, const int* params, float* out_src,
+                                   float* out_tgt, int B, int Hs, int Ws, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
