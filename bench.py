@@ -152,7 +152,7 @@ def main() -> None:
                                    f"batch {B}/GPU, sample+fwd+loss+bwd+allreduce+Adam",
                        "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
                        "final_loss": round(float(loss), 6)},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fwd + dgrad launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/hbm_traffic_current.json)",

@@ -1,10 +1,9 @@
 // The two bandwidth-bound convolutions at the ends of the U-Net.
 //
-//   * stem: Conv3x3(pad 1) from the image tensor (NCHW fp32, Cin <= 8; 3 for RGB tiles) to NHWC
-//     features -- the first conv of SharedEncoder.inc (src/models/components/shared_encoder.py:15,67).
-//     K = 9*Cin = 27 is too thin for an MFMA tile and the layer is bound by writing the output, so it is
-//     a direct VALU convolution: one thread per output pixel, weights broadcast from LDS, the 3x3xCin
-//     patch in registers, 16 output channels at a time; it also emits the BatchNorm partial sums.
+//   * stem: Conv3x3(pad 1) from the image tensor (NCHW fp32, Cin <= 3) to NHWC features -- the first conv of
+//     SharedEncoder.inc (src/models/components/shared_encoder.py:15,67).  Forward: one K = 32 MFMA step on an
+//     im2col patch built in LDS (kernel in conv3x3_mfma.hip, next to the shared epilogue); weight/bias gradient:
+//     the MFMA kernel below.  The layer is bound by moving its 64-channel output / gradient.
 //   * head: Conv1x1 from NHWC features to the NCHW fp32 velocity field -- FlowMatchingDecoder.outc
 //     (src/models/components/task_decoders.py:100,132), Cout <= 4.
 // and their backward passes (weight / bias gradients; the stem needs no data gradient).
@@ -13,70 +12,6 @@
 namespace {
 
 constexpr int STEM_MAX_CIN = 8;
-
-// ---------------------------------------------------------------------------------------------
-// stem forward
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, T* __restrict__ y, int ldy,
-                                                       float* __restrict__ stat_part, int B, int H, int W, int Cin,
-                                                       int Cout) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wl = reinterpret_cast<float*>(smem);            // [Cout][Cin*9]
-  float* red = wl + Cout * Cin * 9;                      // [4 waves][2][Cout]
-  const int K = Cin * 9;
-  for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = w[i];
-  __syncthreads();
-  const long npix = (long)B * H * W;
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool ok = p < npix;
-  const int px = ok ? (int)(p % W) : 0;
-  const int py = ok ? (int)((p / W) % H) : 0;
-  const int n = ok ? (int)(p / ((long)W * H)) : 0;
-  float patch[STEM_MAX_CIN * 9];
-#pragma unroll
-  for (int ci = 0; ci < STEM_MAX_CIN; ++ci)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      patch[ci * 9 + t] = (ok && ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                              ? x[(((long)n * Cin + ci) * H + yy) * W + xx] : 0.f;
-    }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c0 = 0; c0 < Cout; c0 += 8) {
-    f32x8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float acc = 0.f;
-      const float* wr = wl + (c0 + k) * K;
-#pragma unroll
-      for (int ci = 0; ci < STEM_MAX_CIN; ++ci)
-        if (ci < Cin)
-#pragma unroll
-          for (int t = 0; t < 9; ++t) acc = fmaf(patch[ci * 9 + t], wr[ci * 9 + t], acc);
-      o.v[k] = acc + (bias ? bias[c0 + k] : 0.f);
-    }
-    if (ok) store8(y + p * ldy + c0, o);
-    if (stat_part) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float v = ok ? o.v[k] : 0.f;
-        const float s1 = wave_sum(v), s2 = wave_sum(v * v);
-        if (lane == 0) { red[(wave * 2 + 0) * Cout + c0 + k] = s1; red[(wave * 2 + 1) * Cout + c0 + k] = s2; }
-      }
-    }
-  }
-  if (stat_part) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
-      const int which = i / Cout, c = i - which * Cout;
-      float s = 0.f;
-      for (int k = 0; k < 4; ++k) s += red[(k * 2 + which) * Cout + c];
-      stat_part[((long)blockIdx.x * 2 + which) * Cout + c] = s;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // stem weight / bias gradient on MFMA:
