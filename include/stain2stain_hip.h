@@ -154,6 +154,13 @@ int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accum
 int s2s_paired_crop_flip_normalize(const void* src_u8, const void* tgt_u8, const int* params, float* out_src,
                                    float* out_tgt, int B, int Hs, int Ws, int S, void* stream);
 
+/* ---- segmentation loss (seg_loss.hip) -- SURVEY section 8 row f2 --------------------------------------
+ * seg = dw * DiceLoss(sigmoid(z), g) + (1-dw) * BCEWithLogits(z, g)  (conditional_flow_matching_multitask.py:36-53,
+ * 174-202).  z, g: float[n]; out: float[3] = {seg, dice, bce}; dz (optional) = grad_scale * d seg / dz;
+ * work: double[512*4 + 4]. */
+int s2s_seg_loss(const float* z, const float* g, float* dz, float* out, double* work, long n, float smooth,
+                 float dice_weight, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

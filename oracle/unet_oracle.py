@@ -35,6 +35,12 @@ Reference lines each function follows (relative to the reference checkout):
                           via conditional_flow_matching.py:112-131
 * ``euler_sample``        BASELINE.json config 4 (fixed-step Euler over the eval-mode net;
                           the reference's dopri5 lives in torchdyn, absent)
+* ``seg_decoder_forward`` src/models/components/task_decoders.py:171-194 (SegmentationDecoder)
+* ``dice_loss`` / ``bce_with_logits`` / ``seg_loss``
+                          src/models/conditional_flow_matching_multitask.py:36-53, :119, :174-202
+* ``multitask_loss_and_grads``  :204-257 (flow term on xt, mask head on the source image,
+                          total = flow + seg_loss_weight * seg; the encoder runs twice, so its
+                          BatchNorm running statistics advance twice per step)
 """
 from __future__ import annotations
 
@@ -194,6 +200,51 @@ def decoder_forward(bottleneck: Tensor, skips: Sequence[Tensor], t_emb: Tensor, 
     for i, skip in enumerate(skips):
         x = up_block(x, skip, P, f"{dec}.ups.{i}", training, new_buffers)
     return F.conv2d(x, P[f"{dec}.outc.weight"], P[f"{dec}.outc.bias"])
+
+
+def seg_decoder_forward(bottleneck: Tensor, skips: Sequence[Tensor], P: Params, training: bool,
+                        new_buffers: Optional[Params] = None, dec: str = "seg_decoder") -> Tensor:
+    x = bottleneck
+    for i, skip in enumerate(skips):
+        x = up_block(x, skip, P, f"{dec}.ups.{i}", training, new_buffers)
+    return F.conv2d(x, P[f"{dec}.outc.weight"], P[f"{dec}.outc.bias"])
+
+
+def dice_loss(logits: Tensor, target: Tensor, smooth: float = 1.0) -> Tensor:
+    p = torch.sigmoid(logits).reshape(-1)
+    g = target.reshape(-1)
+    inter = (p * g).sum()
+    return 1 - (2.0 * inter + smooth) / (p.sum() + g.sum() + smooth)
+
+
+def bce_with_logits(logits: Tensor, target: Tensor) -> Tensor:
+    z, g = logits.reshape(-1), target.reshape(-1)
+    return (z.clamp_min(0) - z * g + torch.log1p(torch.exp(-z.abs()))).mean()
+
+
+def seg_loss(logits: Tensor, target: Tensor, dice_weight: float = 0.5, smooth: float = 1.0):
+    target = target.float()
+    d, b = dice_loss(logits, target, smooth), bce_with_logits(logits, target)
+    return dice_weight * d + (1 - dice_weight) * b, d, b
+
+
+def multitask_loss_and_grads(P: Params, x0: Tensor, x1: Tensor, t: Tensor, mask: Tensor,
+                             seg_loss_weight: float = 1.0, dice_weight: float = 0.5):
+    """One training-mode forward/backward of the multitask step.  Returns (losses dict, grads, new_buffers)."""
+    keys = trainable_keys(P)
+    Q = dict(P)
+    for k in keys:
+        Q[k] = P[k].detach().clone().requires_grad_(True)
+    nb: Params = {}
+    xt, ut = cfm_sample(x0, x1, t)
+    flow = cfm_loss(flow_forward(t, xt, Q, True, nb), ut)
+    b, skips = encoder_forward(x0, Q, True, nb)
+    seg, d, bce = seg_loss(seg_decoder_forward(b, skips, Q, True, nb), mask, dice_weight)
+    total = flow + seg_loss_weight * seg
+    gs = torch.autograd.grad(total, [Q[k] for k in keys])
+    losses = {"total": total.detach(), "flow": flow.detach(), "seg": seg.detach(), "dice": d.detach(),
+              "bce": bce.detach()}
+    return losses, dict(zip(keys, gs)), nb
 
 
 def flow_forward(t: Tensor, x: Tensor, P: Params, training: bool,

@@ -219,6 +219,62 @@ class FlowMatchingDecoder(nn.Module):
         return _DecoderFn.apply(self, len(skips), bottleneck, t_emb, *skips, *self.parameters())
 
 
+class _SegDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: "SegmentationDecoder", n_skips: int, bottleneck, *rest):
+        skips = rest[:n_skips]
+        dt = mod.compute_dtype
+        dctx = engine.decoder_forward(mod, _as_nhwc(bottleneck.detach(), dt), [_as_nhwc(s.detach(), dt) for s in skips],
+                                      None, dt, mod.training)
+        ctx.mod, ctx.dctx = mod, dctx
+        return dctx.v
+
+    @staticmethod
+    def backward(ctx, dv):
+        mod, dctx = ctx.mod, ctx.dctx
+        if dctx.layers and dctx.layers[0][0] is None:
+            raise RuntimeError("stain2stain_amd: backward through an eval-mode forward is not supported")
+        named = list(mod.named_parameters())
+        grads = _fresh_grads(named)
+        dbott, dskips, _ = engine.decoder_backward(mod, dctx, dv.contiguous().float(), grads)
+        ctx.dctx = None
+        outs = (None, None, dbott.permute(0, 3, 1, 2)) + tuple(d.permute(0, 3, 1, 2) for d in dskips)
+        return outs + tuple(grads[n] for n, _ in named)
+
+
+class SegmentationDecoder(nn.Module):
+    """Mask head (reference src/models/components/task_decoders.py:137-194): N x Up(bilinear x2, cat skip,
+    DoubleConv) -> Conv1x1, no time conditioning.  forward(bottleneck, skips) -> logits [B, out_channels, H, W]."""
+
+    def __init__(self, bottleneck_channels: int = 1024, features: Optional[List[int]] = None, out_channels: int = 1,
+                 bilinear: bool = True, precision: str = "bf16"):
+        super().__init__()
+        if features is None:
+            features = [512, 256, 128, 64]
+        features = list(features)
+        if not bilinear:
+            raise NotImplementedError("bilinear=False (ConvTranspose2d) is a dead branch in the reference configs")
+        _check_channels([bottleneck_channels] + features)
+        if out_channels > 4:
+            raise ValueError("stain2stain_amd head kernel supports at most 4 output channels")
+        self.compute_dtype = _resolve_precision(precision)
+        self.time_mlp = None
+        self.ups = nn.ModuleList()
+        in_ch = bottleneck_channels
+        for feat in features:
+            up = nn.Module()
+            up.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            up.conv = _double_conv_container(in_ch + feat, feat)
+            self.ups.append(up)
+            in_ch = feat
+        self.outc = nn.Conv2d(features[-1], out_channels, kernel_size=1)
+        self.up_blocks = [_bundles(u.conv, f"ups.{i}.conv") for i, u in enumerate(self.ups)]
+
+    def forward(self, bottleneck: torch.Tensor, skip_connections: List[torch.Tensor]):
+        skips = list(skip_connections)[: len(self.ups)]
+        return _SegDecoderFn.apply(self, len(skips), bottleneck, *skips, *self.parameters())
+
+
 # ------------------------------------------------------------------------------------------------
 class FlowUNet(nn.Module):
     """``net(t, x, y=None, **kwargs) -> v``: encoder + time embedding + flow decoder in one module.

@@ -212,11 +212,13 @@ def decoder_forward(dec, bottleneck: torch.Tensor, skips: Sequence[torch.Tensor]
     """dec: FlowMatchingDecoder container (time_mlp, time_proj, up_blocks, outc).  with_head=False stops at the
     last activation (ctx.lows[-1]); the fused head+loss kernel of the training step takes it from there."""
     ctx = DecCtx(dtype, t_emb)
-    l0, l2 = dec.time_mlp[0], dec.time_mlp[2]
-    ctx.h1 = ops.linear_fwd(t_emb, l0.weight.detach(), l0.bias.detach())
-    ctx.a1 = ops.silu_fwd(ctx.h1)
-    ctx.h2 = ops.linear_fwd(ctx.a1, l2.weight.detach(), l2.bias.detach())
-    tbias = ops.linear_fwd(ctx.h2, dec.time_proj.weight.detach(), dec.time_proj.bias.detach())  # [B, Cb]
+    tbias = None
+    if getattr(dec, "time_mlp", None) is not None:      # the segmentation head has no time conditioning
+        l0, l2 = dec.time_mlp[0], dec.time_mlp[2]
+        ctx.h1 = ops.linear_fwd(t_emb, l0.weight.detach(), l0.bias.detach())
+        ctx.a1 = ops.silu_fwd(ctx.h1)
+        ctx.h2 = ops.linear_fwd(ctx.a1, l2.weight.detach(), l2.bias.detach())
+        tbias = ops.linear_fwd(ctx.h2, dec.time_proj.weight.detach(), dec.time_proj.bias.detach())  # [B, Cb]
     x = bottleneck
     for i, ((c1, c2), skip) in enumerate(zip(dec.up_blocks, skips)):
         B, Hs, Ws, _ = skip.shape
@@ -259,6 +261,10 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
         if on_group_done is not None:
             on_group_done(nup - i)
     dbott = g
+    if getattr(dec, "time_mlp", None) is None:
+        if on_group_done is not None:
+            on_group_done(nup + 1)
+        return dbott, dskips, None
     # time path: tbias was broadcast-added to the bottleneck before the first up-sampling
     dtb = ops.pixel_sum(g)
     l0, l2 = dec.time_mlp[0], dec.time_mlp[2]

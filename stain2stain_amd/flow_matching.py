@@ -120,3 +120,92 @@ class ConditionalFlowMatchingModule(_Base):
     @torch.no_grad()
     def generate(self, source_img: torch.Tensor, num_steps: int = 100) -> torch.Tensor:
         return euler_generate(self.net, source_img, num_steps)
+
+
+class _SegLoss(torch.autograd.Function):
+    """dw * Dice(sigmoid(z), g) + (1-dw) * BCEWithLogits(z, g) with the fused two-pass kernel."""
+
+    @staticmethod
+    def forward(ctx, z: torch.Tensor, g: torch.Tensor, smooth: float, dice_weight: float):
+        out, dz = ops.seg_loss(z.detach().float(), g.detach(), smooth, dice_weight, want_grad=True)
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(out[1], out[2])
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, gseg, gdice, gbce):
+        (dz,) = ctx.saved_tensors
+        return dz * gseg, None, None, None
+
+
+class MultiTaskFlowMatchingModule(_Base):
+    """Same surface as the reference's MultiTaskFlowMatchingLitModule
+    (src/models/conditional_flow_matching_multitask.py:57-257,391-417): shared encoder, flow head A, mask head B,
+    L = L_FM + seg_loss_weight * (dice_weight * Dice + (1 - dice_weight) * BCE).  Logging hooks left out."""
+
+    def __init__(self, encoder, flow_decoder, seg_decoder, flow_matcher: Optional[ConditionalFlowMatcher] = None,
+                 solver=None, optimizer=None, scheduler=None, compile: bool = False, log_images: bool = False,
+                 seg_loss_weight: float = 1.0, dice_weight: float = 0.5, n_images_log: int = 5,
+                 time_emb_dim: int = 256):
+        super().__init__()
+        from .components import TimeEmbedding
+        self.encoder, self.flow_decoder, self.seg_decoder = encoder, flow_decoder, seg_decoder
+        self.time_embedding = TimeEmbedding(time_emb_dim)
+        self.flow_matcher = flow_matcher or ConditionalFlowMatcher(0.0)
+        self.solver, self.optimizer, self.scheduler = solver, optimizer, scheduler
+        self.seg_loss_weight, self.dice_weight = seg_loss_weight, dice_weight
+        self.dice_smooth = 1.0
+
+    def forward_flow(self, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        bottleneck, skips = self.encoder(x)
+        return self.flow_decoder(bottleneck, skips, self.time_embedding(t))
+
+    def forward_segmentation(self, x: torch.Tensor) -> torch.Tensor:
+        bottleneck, skips = self.encoder(x)
+        return self.seg_decoder(bottleneck, skips)
+
+    def compute_segmentation_loss(self, pred_mask: torch.Tensor, target_mask: torch.Tensor):
+        seg, dice, bce = _SegLoss.apply(pred_mask, target_mask.float(), self.dice_smooth, self.dice_weight)
+        return seg, {"dice": dice, "bce": bce, "seg_total": seg}
+
+    def model_step(self, batch):
+        source_img, target_img, gt_mask = batch
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(source_img, target_img)
+        flow_loss = _MSE.apply(self.forward_flow(t, xt), ut)
+        seg_loss, d = self.compute_segmentation_loss(self.forward_segmentation(source_img), gt_mask)
+        total = flow_loss + self.seg_loss_weight * seg_loss
+        return total, {"total": total, "flow": flow_loss, "seg": seg_loss, "seg_dice": d["dice"], "seg_bce": d["bce"]}
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        loss, d = self.model_step(batch)
+        for k, v in d.items():
+            self.log(f"train/{k}_loss", v, on_step=True, on_epoch=True, prog_bar=(k == "total"), sync_dist=True)
+        return loss
+
+    def configure_optimizers(self) -> Dict[str, Any]:
+        params = (list(self.encoder.parameters()) + list(self.flow_decoder.parameters())
+                  + list(self.seg_decoder.parameters()))
+        optimizer = self.optimizer(params=params)
+        if self.scheduler is not None:
+            return {"optimizer": optimizer,
+                    "lr_scheduler": {"scheduler": self.scheduler(optimizer=optimizer), "monitor": "val/loss",
+                                     "interval": "epoch", "frequency": 1}}
+        return {"optimizer": optimizer}
+
+    @torch.no_grad()
+    def generate(self, source_img: torch.Tensor, num_steps: int = 100):
+        """(generated image by fixed-step Euler, mask probabilities) like the reference's generate (:419-484)."""
+        self.eval()
+        if source_img.dim() == 3:
+            source_img = source_img.unsqueeze(0)
+        pred_mask = torch.sigmoid(self.forward_segmentation(source_img))
+
+        class _Net(torch.nn.Module):
+            def __init__(s, outer):
+                super().__init__()
+                s.outer = outer
+
+            def forward(s, t, x):
+                return s.outer.forward_flow(t, x)
+
+        return euler_generate(_Net(self), source_img, num_steps), pred_mask

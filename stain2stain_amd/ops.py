@@ -424,6 +424,19 @@ def mse_loss(v: torch.Tensor, u: torch.Tensor, want_grad: bool = True, grad_scal
     return loss, dv
 
 
+def seg_loss(z: torch.Tensor, g: torch.Tensor, smooth: float = 1.0, dice_weight: float = 0.5, want_grad: bool = True,
+             grad_scale: float = 1.0):
+    """Dice + BCE-with-logits on a logit map; returns (out[3] = seg, dice, bce; dz or None)."""
+    z = z.contiguous()
+    g = g.to(torch.float32).contiguous()
+    out = torch.empty((3,), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    work = torch.empty((512 * 4 + 4,), dtype=torch.float64, device=z.device)
+    _native.check(_L().s2s_seg_loss(_f32(z), _f32(g), _f32(dz), _f32(out), work.data_ptr(), z.numel(), float(smooth),
+                                    float(dice_weight), float(grad_scale), _stream()), "seg_loss")
+    return out, dz
+
+
 def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:
     _native.check(_L().s2s_axpy(_f32(x), _f32(y), float(a), x.numel(), _stream()), "axpy")
 

@@ -25,7 +25,7 @@ import torch
 REF = os.environ.get("S2S_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 from src.models.components.shared_encoder import DoubleConv, Down, SharedEncoder, TimeEmbedding  # noqa: E402
-from src.models.components.task_decoders import FlowMatchingDecoder, Up  # noqa: E402
+from src.models.components.task_decoders import FlowMatchingDecoder, SegmentationDecoder, Up  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 1984  # configs/experiment/gray_matter/simple_flow_matching.yaml:16
@@ -165,6 +165,51 @@ def make_ops_fixture():
     print("ops.npz", len(out), "arrays")
 
 
+def make_multitask_fixture():
+    """Row f2.  Networks are the reference's own classes; the loss classes sit in a module that imports lightning /
+    torchcfm / wandb (not installed), so DiceLoss.forward (conditional_flow_matching_multitask.py:36-53),
+    nn.BCEWithLogitsLoss (:119) and the combination at :191-246 are driven from here with stock torch ops."""
+    torch.manual_seed(SEED + 2)
+    feats, tdim, B, HW = (16, 32), 32, 4, 64
+    enc = SharedEncoder(3, list(feats))
+    fdec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
+    sdec = SegmentationDecoder(feats[-1], list(feats[:-1][::-1]), 1)
+    temb = TimeEmbedding(tdim)
+    g = torch.Generator().manual_seed(SEED + 2)
+    out = {}
+    mods = (("encoder.", enc), ("flow_decoder.", fdec), ("seg_decoder.", sdec))
+    for pre, m in mods:
+        for k, v in m.state_dict().items():
+            out["init/" + pre + k] = npy(v)
+    x0 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+    x1 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+    t = torch.rand(B, generator=g)
+    mask = (torch.rand(B, 1, HW, HW, generator=g) > 0.7).float()
+    tb = t.view(-1, 1, 1, 1)
+    xt, ut = tb * x1 + (1 - tb) * x0, x1 - x0
+    for m in (enc, fdec, sdec):
+        m.train()
+    b, skips = enc(xt)
+    flow = torch.mean((fdec(b, skips, temb(t)) - ut) ** 2)
+    b2, skips2 = enc(x0)
+    logits = sdec(b2, skips2)
+    p = torch.sigmoid(logits).view(-1); gt = mask.view(-1)
+    dice = 1 - (2.0 * (p * gt).sum() + 1.0) / (p.sum() + gt.sum() + 1.0)
+    bce = torch.nn.BCEWithLogitsLoss()(logits, mask)
+    seg = 0.5 * dice + 0.5 * bce
+    total = flow + 1.0 * seg
+    total.backward()
+    out.update({"x0": npy(x0), "x1": npy(x1), "t": npy(t), "mask": npy(mask), "logits": npy(logits),
+                "loss/total": npy(total), "loss/flow": npy(flow), "loss/dice": npy(dice), "loss/bce": npy(bce)})
+    for pre, m in mods:
+        for k, prm in m.named_parameters():
+            out["grad/" + pre + k] = npy(prm.grad)
+        for k, v in m.state_dict().items():
+            out["after/" + pre + k] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "multitask_step.npz"), **out)
+    print("multitask_step.npz", {k: float(out[k]) for k in out if k.startswith("loss/")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
@@ -172,3 +217,4 @@ if __name__ == "__main__":
     # three levels, non-square, odd at level 1 (38 -> 19 -> 9; 9*2=18 vs 19 -> pad branch)
     make_step_fixture("odd3_step.npz", (8, 16, 24), (38, 44), 2, 1, 16)
     make_ops_fixture()
+    make_multitask_fixture()

@@ -121,3 +121,21 @@ def test_up_block_with_pad(golden_ops):
 def test_bilinear_and_pool(golden_ops):
     assert relerr(O.upsample2x_bilinear_ac(golden_ops["bilinear/x"]), golden_ops["bilinear/y"]) < 1e-6
     assert torch.equal(O.maxpool2(golden_ops["pool/x"]), golden_ops["pool/y"])
+
+
+def test_multitask_step_matches_reference():
+    """Row f2: shared encoder run twice, flow head + mask head, Dice + BCE."""
+    from conftest import load_golden
+    G = load_golden("multitask_step.npz")
+    P = sub(G, "init/")
+    losses, grads, nb = O.multitask_loss_and_grads(P, G["x0"], G["x1"], G["t"], G["mask"], 1.0, 0.5)
+    for k in ("total", "flow", "dice", "bce"):
+        assert relerr(losses[k], G["loss/" + k]) < FWD_TOL, k
+    gref = sub(G, "grad/")
+    gscale = max(float(v.abs().max()) for v in gref.values())
+    for k, g in grads.items():
+        assert _grad_ok(g, gref[k], 1e-3 * gscale), k
+    for k, v in nb.items():
+        ref = G["after/" + k]
+        assert (int(v) == int(ref)) if k.endswith("tracked") else relerr(v, ref) < FWD_TOL, k
+    assert int(nb["encoder.inc.double_conv.1.num_batches_tracked"]) == 2      # the encoder ran twice
