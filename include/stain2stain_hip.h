@@ -160,6 +160,12 @@ int s2s_paired_crop_flip_normalize(const void* src_u8, const void* tgt_u8, const
  * work: double[512*4 + 4]. */
 int s2s_seg_loss(const float* z, const float* g, float* dz, float* out, double* work, long n, float smooth,
                  float dice_weight, float grad_scale, void* stream);
+/* Multiclass form: dw * MulticlassDiceLoss(softmax(z), t) + (1-dw) * CrossEntropy(z, t, ignore_index)
+ * (conditional_flow_matching_multitask_multiclassloss.py:41-83, 159, 214-245).  z: float[B][C][HW] logits,
+ * target: int64[B][HW]; out: float[3] = {seg, dice, ce}; dz (optional) float[B][C][HW];
+ * work: double[(512 + 1) * 26]; 2 <= C <= 8. */
+int s2s_seg_loss_multiclass(const float* z, const long* target, float* dz, float* out, double* work, long B, long HW,
+                            int C, int ignore_index, float smooth, float dice_weight, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,8 @@ Reference lines each function follows (relative to the reference checkout):
 * ``seg_decoder_forward`` src/models/components/task_decoders.py:171-194 (SegmentationDecoder)
 * ``dice_loss`` / ``bce_with_logits`` / ``seg_loss``
                           src/models/conditional_flow_matching_multitask.py:36-53, :119, :174-202
+* ``multiclass_dice_loss`` / ``seg_loss_multiclass``
+                          src/models/conditional_flow_matching_multitask_multiclassloss.py:41-83, :159, :214-245
 * ``multitask_loss_and_grads``  :204-257 (flow term on xt, mask head on the source image,
                           total = flow + seg_loss_weight * seg; the encoder runs twice, so its
                           BatchNorm running statistics advance twice per step)
@@ -228,8 +230,33 @@ def seg_loss(logits: Tensor, target: Tensor, dice_weight: float = 0.5, smooth: f
     return dice_weight * d + (1 - dice_weight) * b, d, b
 
 
+def multiclass_dice_loss(logits: Tensor, target: Tensor, num_classes: int, smooth: float = 1.0,
+                         ignore_index: int = -100) -> Tensor:
+    """conditional_flow_matching_multitask_multiclassloss.py:41-83."""
+    p = torch.softmax(logits, dim=1)
+    oh = F.one_hot(target.long(), num_classes).permute(0, 3, 1, 2).float()
+    valid = (target != ignore_index).float().unsqueeze(1) if ignore_index >= 0 else torch.ones_like(p[:, :1])
+    scores = []
+    for c in range(num_classes):
+        pc, gc = p[:, c:c + 1] * valid, oh[:, c:c + 1] * valid
+        scores.append((2.0 * (pc * gc).sum() + smooth) / (pc.sum() + gc.sum() + smooth))
+    return 1 - torch.stack(scores).mean()
+
+
+def seg_loss_multiclass(logits: Tensor, target: Tensor, dice_weight: float = 0.5, ignore_index: int = -100,
+                        smooth: float = 1.0):
+    """:214-245 -- dw * Dice + (1-dw) * CrossEntropy(ignore_index)."""
+    if target.dim() == 4 and target.shape[1] == 1:
+        target = target.squeeze(1)
+    target = target.long()
+    d = multiclass_dice_loss(logits, target, logits.shape[1], smooth, ignore_index)
+    ce = F.cross_entropy(logits, target, ignore_index=ignore_index)
+    return dice_weight * d + (1 - dice_weight) * ce, d, ce
+
+
 def multitask_loss_and_grads(P: Params, x0: Tensor, x1: Tensor, t: Tensor, mask: Tensor,
-                             seg_loss_weight: float = 1.0, dice_weight: float = 0.5):
+                             seg_loss_weight: float = 1.0, dice_weight: float = 0.5, multiclass: bool = False,
+                             ignore_index: int = -100):
     """One training-mode forward/backward of the multitask step.  Returns (losses dict, grads, new_buffers)."""
     keys = trainable_keys(P)
     Q = dict(P)
@@ -239,11 +266,13 @@ def multitask_loss_and_grads(P: Params, x0: Tensor, x1: Tensor, t: Tensor, mask:
     xt, ut = cfm_sample(x0, x1, t)
     flow = cfm_loss(flow_forward(t, xt, Q, True, nb), ut)
     b, skips = encoder_forward(x0, Q, True, nb)
-    seg, d, bce = seg_loss(seg_decoder_forward(b, skips, Q, True, nb), mask, dice_weight)
+    logits = seg_decoder_forward(b, skips, Q, True, nb)
+    seg, d, bce = (seg_loss_multiclass(logits, mask, dice_weight, ignore_index) if multiclass
+                   else seg_loss(logits, mask, dice_weight))
     total = flow + seg_loss_weight * seg
     gs = torch.autograd.grad(total, [Q[k] for k in keys])
     losses = {"total": total.detach(), "flow": flow.detach(), "seg": seg.detach(), "dice": d.detach(),
-              "bce": bce.detach()}
+              "bce": bce.detach(), "ce": bce.detach()}
     return losses, dict(zip(keys, gs)), nb
 
 

@@ -255,8 +255,8 @@ class SegmentationDecoder(nn.Module):
         if not bilinear:
             raise NotImplementedError("bilinear=False (ConvTranspose2d) is a dead branch in the reference configs")
         _check_channels([bottleneck_channels] + features)
-        if out_channels > 4:
-            raise ValueError("stain2stain_amd head kernel supports at most 4 output channels")
+        if out_channels > 8:
+            raise ValueError("stain2stain_amd segmentation head kernel supports at most 8 output channels")
         self.compute_dtype = _resolve_precision(precision)
         self.time_mlp = None
         self.ups = nn.ModuleList()

@@ -5,7 +5,7 @@
 //     im2col patch built in LDS (kernel in conv3x3_mfma.hip, next to the shared epilogue); weight/bias gradient:
 //     the MFMA kernel below.  The layer is bound by moving its 64-channel output / gradient.
 //   * head: Conv1x1 from NHWC features to the NCHW fp32 velocity field -- FlowMatchingDecoder.outc
-//     (src/models/components/task_decoders.py:100,132), Cout <= 4.
+//     (src/models/components/task_decoders.py:100,132,169), Cout <= 8 (3 RGB, 1 mask, up to 8 classes).
 // and their backward passes (weight / bias gradients; the stem needs no data gradient).
 #include "common.h"
 
@@ -177,9 +177,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* par
 // ---------------------------------------------------------------------------------------------
 // head: 1x1 conv NHWC -> NCHW fp32
 // ---------------------------------------------------------------------------------------------
-constexpr int HEAD_MAX_COUT = 4;
+constexpr int HEAD_MAX_COUT = 4;      // fused head+loss kernel (flow head, 3 channels)
+constexpr int HEAD_WIDE_COUT = 8;     // plain head kernels (segmentation head: num_classes)
 
-template <typename T>
+template <typename T, int MO>
 __global__ void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                 const float* __restrict__ bias, float* __restrict__ y, long npix, int HW, int C,
                                 int Cout) {
@@ -188,26 +189,26 @@ __global__ void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* _
   for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) wl[i] = w[i];
   __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
-    float acc[HEAD_MAX_COUT];
+    float acc[MO];
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_COUT; ++o) acc[o] = 0.f;
+    for (int o = 0; o < MO; ++o) acc[o] = 0.f;
     for (int c8 = 0; c8 < C; c8 += 8) {
       const f32x8 v = load8(x + p * ldx + c8);
 #pragma unroll
-      for (int o = 0; o < HEAD_MAX_COUT; ++o)
+      for (int o = 0; o < MO; ++o)
         if (o < Cout)
 #pragma unroll
           for (int k = 0; k < 8; ++k) acc[o] = fmaf(v.v[k], wl[o * C + c8 + k], acc[o]);
     }
     const long n = p / HW, q = p - n * HW;
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_COUT; ++o)
+    for (int o = 0; o < MO; ++o)
       if (o < Cout) y[(n * Cout + o) * HW + q] = acc[o] + (bias ? bias[o] : 0.f);
   }
 }
 
 // dX[p][c] = sum_o dY[n][o][q] * W[o][c]
-template <typename T>
+template <typename T, int MO>
 __global__ void head_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
                                      int lddx, long npix, int HW, int C, int Cout) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,16 +217,16 @@ __global__ void head_bwd_data_kernel(const float* __restrict__ dy, const float* 
   __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
     const long n = p / HW, q = p - n * HW;
-    float g[HEAD_MAX_COUT];
+    float g[MO];
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_COUT; ++o) g[o] = o < Cout ? dy[(n * Cout + o) * HW + q] : 0.f;
+    for (int o = 0; o < MO; ++o) g[o] = o < Cout ? dy[(n * Cout + o) * HW + q] : 0.f;
     for (int c8 = 0; c8 < C; c8 += 8) {
       f32x8 v;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float a = 0.f;
 #pragma unroll
-        for (int o = 0; o < HEAD_MAX_COUT; ++o)
+        for (int o = 0; o < MO; ++o)
           if (o < Cout) a = fmaf(g[o], wl[o * C + c8 + k], a);
         v.v[k] = a;
       }
@@ -235,13 +236,13 @@ __global__ void head_bwd_data_kernel(const float* __restrict__ dy, const float* 
 }
 
 // dW[o][c] = sum_p dY[p][o]*X[p][c], db[o] = sum_p dY[p][o]; part[gridDim.x][Cout][C+1]
-template <typename T>
+template <typename T, int MO>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x,
                                                          int ldx, float* __restrict__ part, long npix, int HW, int C,
                                                          int Cout) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xl = reinterpret_cast<float*>(smem);            // [64 px][C+1]
-  float* gl = xl + 64 * (C + 1);                         // [64 px][HEAD_MAX_COUT]
+  float* gl = xl + 64 * (C + 1);                         // [64 px][MO]
   const int nout = Cout * (C + 1);
   float acc[8];                                          // outputs tid, tid+256, ... (nout <= 2048)
 #pragma unroll
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
       const int pp = i / C, c = i - pp * C;
       xl[pp * (C + 1) + c] = (p0 + pp < npix) ? to_f32(x[(p0 + pp) * ldx + c]) : 0.f;
     }
-    for (int i = threadIdx.x; i < 64 * HEAD_MAX_COUT; i += 256) {
-      const int pp = i / HEAD_MAX_COUT, o = i - pp * HEAD_MAX_COUT;
+    for (int i = threadIdx.x; i < 64 * MO; i += 256) {
+      const int pp = i / MO, o = i - pp * MO;
       float v = 0.f;
       if (o < Cout && p0 + pp < npix) {
         const long p = p0 + pp, n = p / HW, q = p - n * HW;
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
       if (id < nout) {
         const int o = id / (C + 1), c = id - o * (C + 1);
         float a = acc[i];
-        if (c < C) for (int pp = 0; pp < 64; ++pp) a = fmaf(gl[pp * HEAD_MAX_COUT + o], xl[pp * (C + 1) + c], a);
-        else for (int pp = 0; pp < 64; ++pp) a += gl[pp * HEAD_MAX_COUT + o];
+        if (c < C) for (int pp = 0; pp < 64; ++pp) a = fmaf(gl[pp * MO + o], xl[pp * (C + 1) + c], a);
+        else for (int pp = 0; pp < 64; ++pp) a += gl[pp * MO + o];
         acc[i] = a;
       }
     }
@@ -485,19 +486,19 @@ extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const
 extern "C" int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias,
                                     float* y_nchw, int B, int H, int W, int C, int Cout, void* stream) {
   if (!x || !w || !y_nchw) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || Cout <= 0 || Cout > HEAD_MAX_COUT)
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || Cout <= 0 || Cout > HEAD_WIDE_COUT)
     return S2S_ERR_SHAPE;
   const long npix = (long)B * H * W;
   long grid = (npix + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((int)grid), dim3(256), Cout * C * 4, s, (const bf16_t*)x, ldx, w,
-                       bias, y_nchw, npix, H * W, C, Cout);
-  else if (dtype == S2S_F32)
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((int)grid), dim3(256), Cout * C * 4, s, (const float*)x, ldx, w,
-                       bias, y_nchw, npix, H * W, C, Cout);
+#define S2S_HEAD_FWD(TT, MO)                                                                                        \
+  hipLaunchKernelGGL((head_fwd_kernel<TT, MO>), dim3((int)grid), dim3(256), Cout * C * 4, s, (const TT*)x, ldx, w, \
+                     bias, y_nchw, npix, H * W, C, Cout)
+  if (dtype == S2S_BF16) { if (Cout <= 4) S2S_HEAD_FWD(bf16_t, 4); else S2S_HEAD_FWD(bf16_t, 8); }
+  else if (dtype == S2S_F32) { if (Cout <= 4) S2S_HEAD_FWD(float, 4); else S2S_HEAD_FWD(float, 8); }
   else return S2S_ERR_DTYPE;
+#undef S2S_HEAD_FWD
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -513,22 +514,23 @@ extern "C" int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void*
                                     int lddx, float* part, float* dw, float* dbias, int accumulate, int B, int H, int W,
                                     int C, int Cout, void* stream) {
   if (!dy_nchw || !x || !w || !dx || !part || !dw) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) || Cout <= 0 || Cout > HEAD_MAX_COUT)
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) || Cout <= 0 || Cout > HEAD_WIDE_COUT)
     return S2S_ERR_SHAPE;
   if (Cout * (C + 1) > 2048) return S2S_ERR_SHAPE;
   const long npix = (long)B * H * W;
   long grid = (npix + 255) / 256;
   if (grid > 4096) grid = 4096;
   const int nb = s2s_head_wgrad_blocks(B, H, W);
-  const int lds = (64 * (C + 1) + 64 * HEAD_MAX_COUT) * 4;
+  const int mo = Cout <= 4 ? 4 : 8;
+  const int lds = (64 * (C + 1) + 64 * mo) * 4;
   hipStream_t s = (hipStream_t)stream;
-#define S2S_HEAD_BWD(TT)                                                                                         \
-  hipLaunchKernelGGL(head_bwd_data_kernel<TT>, dim3((int)grid), dim3(256), Cout * C * 4, s, dy_nchw, w, (TT*)dx, \
-                     lddx, npix, H * W, C, Cout);                                                                \
-  hipLaunchKernelGGL(head_wgrad_kernel<TT>, dim3(nb), dim3(256), lds, s, dy_nchw, (const TT*)x, ldx, part, npix, \
-                     H * W, C, Cout);
-  if (dtype == S2S_BF16) { S2S_HEAD_BWD(bf16_t) }
-  else if (dtype == S2S_F32) { S2S_HEAD_BWD(float) }
+#define S2S_HEAD_BWD(TT, MO)                                                                                       \
+  hipLaunchKernelGGL((head_bwd_data_kernel<TT, MO>), dim3((int)grid), dim3(256), Cout * C * 4, s, dy_nchw, w,      \
+                     (TT*)dx, lddx, npix, H * W, C, Cout);                                                         \
+  hipLaunchKernelGGL((head_wgrad_kernel<TT, MO>), dim3(nb), dim3(256), lds, s, dy_nchw, (const TT*)x, ldx, part,   \
+                     npix, H * W, C, Cout);
+  if (dtype == S2S_BF16) { if (mo == 4) { S2S_HEAD_BWD(bf16_t, 4) } else { S2S_HEAD_BWD(bf16_t, 8) } }
+  else if (dtype == S2S_F32) { if (mo == 4) { S2S_HEAD_BWD(float, 4) } else { S2S_HEAD_BWD(float, 8) } }
   else return S2S_ERR_DTYPE;
 #undef S2S_HEAD_BWD
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,

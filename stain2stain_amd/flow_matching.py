@@ -138,6 +138,23 @@ class _SegLoss(torch.autograd.Function):
         return dz * gseg, None, None, None
 
 
+class _SegLossMulticlass(torch.autograd.Function):
+    """dw * softmax-Dice + (1-dw) * CrossEntropy on class-index targets."""
+
+    @staticmethod
+    def forward(ctx, z: torch.Tensor, target: torch.Tensor, ignore_index: int, smooth: float, dice_weight: float):
+        out, dz = ops.seg_loss_multiclass(z.detach().float(), target, ignore_index, smooth, dice_weight,
+                                          want_grad=True)
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(out[1], out[2])
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, gseg, gdice, gce):
+        (dz,) = ctx.saved_tensors
+        return dz * gseg, None, None, None, None
+
+
 class MultiTaskFlowMatchingModule(_Base):
     """Same surface as the reference's MultiTaskFlowMatchingLitModule
     (src/models/conditional_flow_matching_multitask.py:57-257,391-417): shared encoder, flow head A, mask head B,
@@ -146,8 +163,12 @@ class MultiTaskFlowMatchingModule(_Base):
     def __init__(self, encoder, flow_decoder, seg_decoder, flow_matcher: Optional[ConditionalFlowMatcher] = None,
                  solver=None, optimizer=None, scheduler=None, compile: bool = False, log_images: bool = False,
                  seg_loss_weight: float = 1.0, dice_weight: float = 0.5, n_images_log: int = 5,
-                 time_emb_dim: int = 256):
+                 time_emb_dim: int = 256, num_classes: Optional[int] = None, ignore_index: int = -100):
+        """``num_classes`` None: binary mask head, Dice + BCE (conditional_flow_matching_multitask.py).  An integer
+        selects the multiclass form, softmax Dice + CrossEntropy on class-index masks
+        (conditional_flow_matching_multitask_multiclassloss.py:92-159)."""
         super().__init__()
+        self.num_classes, self.ignore_index = num_classes, ignore_index
         from .components import TimeEmbedding
         self.encoder, self.flow_decoder, self.seg_decoder = encoder, flow_decoder, seg_decoder
         self.time_embedding = TimeEmbedding(time_emb_dim)
@@ -165,6 +186,12 @@ class MultiTaskFlowMatchingModule(_Base):
         return self.seg_decoder(bottleneck, skips)
 
     def compute_segmentation_loss(self, pred_mask: torch.Tensor, target_mask: torch.Tensor):
+        if self.num_classes is not None:
+            if target_mask.dim() == 4 and target_mask.shape[1] == 1:
+                target_mask = target_mask.squeeze(1)
+            seg, dice, ce = _SegLossMulticlass.apply(pred_mask, target_mask.long(), self.ignore_index,
+                                                     self.dice_smooth, self.dice_weight)
+            return seg, {"dice": dice, "ce": ce, "seg_total": seg}
         seg, dice, bce = _SegLoss.apply(pred_mask, target_mask.float(), self.dice_smooth, self.dice_weight)
         return seg, {"dice": dice, "bce": bce, "seg_total": seg}
 
@@ -174,7 +201,9 @@ class MultiTaskFlowMatchingModule(_Base):
         flow_loss = _MSE.apply(self.forward_flow(t, xt), ut)
         seg_loss, d = self.compute_segmentation_loss(self.forward_segmentation(source_img), gt_mask)
         total = flow_loss + self.seg_loss_weight * seg_loss
-        return total, {"total": total, "flow": flow_loss, "seg": seg_loss, "seg_dice": d["dice"], "seg_bce": d["bce"]}
+        second = "ce" if self.num_classes is not None else "bce"
+        return total, {"total": total, "flow": flow_loss, "seg": seg_loss, "seg_dice": d["dice"],
+                       "seg_" + second: d[second]}
 
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
         loss, d = self.model_step(batch)
@@ -198,7 +227,11 @@ class MultiTaskFlowMatchingModule(_Base):
         self.eval()
         if source_img.dim() == 3:
             source_img = source_img.unsqueeze(0)
-        pred_mask = torch.sigmoid(self.forward_segmentation(source_img))
+        logits = self.forward_segmentation(source_img)
+        if self.num_classes is not None:       # class map, as the multiclass reference returns (:536-537)
+            pred_mask = torch.argmax(torch.softmax(logits, dim=1), dim=1, keepdim=True)
+        else:
+            pred_mask = torch.sigmoid(logits)
 
         class _Net(torch.nn.Module):
             def __init__(s, outer):

@@ -437,6 +437,31 @@ def seg_loss(z: torch.Tensor, g: torch.Tensor, smooth: float = 1.0, dice_weight:
     return out, dz
 
 
+def seg_loss_multiclass(z: torch.Tensor, target: torch.Tensor, ignore_index: int = -100, smooth: float = 1.0,
+                        dice_weight: float = 0.5, want_grad: bool = True, grad_scale: float = 1.0,
+                        validate: bool = True):
+    """Softmax Dice (mean over classes) + cross entropy on [B,C,H,W] logits and [B,H,W] class indices;
+    returns (out[3] = seg, dice, ce; dz or None).  ``validate`` reproduces the reference's failure on labels
+    outside [0, C) (F.one_hot raises there) at the cost of one host sync."""
+    if z.dim() != 4 or target.dim() != 3 or target.shape != (z.shape[0], z.shape[2], z.shape[3]):
+        raise RuntimeError("stain2stain_amd: seg_loss_multiclass wants logits [B,C,H,W] and target [B,H,W]")
+    B, C, H, W = z.shape
+    z = z.contiguous()
+    target = target.to(torch.int64).contiguous()
+    if validate:
+        lo, hi = int(target.min()), int(target.max())
+        if lo < 0 or hi >= C:
+            raise RuntimeError(f"stain2stain_amd: class index out of range [0, {C}) in segmentation target "
+                               f"(min {lo}, max {hi})")
+    out = torch.empty((3,), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    work = torch.empty((513 * 26,), dtype=torch.float64, device=z.device)
+    _native.check(_L().s2s_seg_loss_multiclass(_f32(z), target.data_ptr(), _f32(dz), _f32(out), work.data_ptr(), B,
+                                               H * W, C, int(ignore_index), float(smooth), float(dice_weight),
+                                               float(grad_scale), _stream()), "seg_loss_multiclass")
+    return out, dz
+
+
 def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:
     _native.check(_L().s2s_axpy(_f32(x), _f32(y), float(a), x.numel(), _stream()), "axpy")
 

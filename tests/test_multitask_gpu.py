@@ -107,3 +107,74 @@ def test_model_step_and_generate(G):
     img, pm = mod.generate(x0[:2], num_steps=3)
     assert img.shape == (2, 3, 64, 64) and pm.shape == (2, 1, 64, 64)
     assert float(pm.min()) >= 0 and float(pm.max()) <= 1
+
+
+# ---- multiclass form ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def GM():
+    return load_golden("multiclass_step.npz")
+
+
+def test_multiclass_loss_kernel_matches_golden(GM):
+    from stain2stain_amd import ops
+    out, dz = ops.seg_loss_multiclass(GM["lossop/z"].to(DEV), GM["lossop/target"].to(DEV), ignore_index=2,
+                                      dice_weight=0.3)
+    assert relerr(out[1], GM["lossop/dice"]) < 1e-5 and relerr(out[2], GM["lossop/ce"]) < 1e-5
+    assert relerr(dz, GM["lossop/dz"]) < 1e-4
+
+
+@pytest.mark.parametrize("C", [2, 3, 5, 8])
+@pytest.mark.parametrize("ignore", [-100, 1])
+def test_multiclass_loss_kernel_matches_oracle(C, ignore):
+    from oracle import unet_oracle as O
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(C)
+    z = torch.randn(3, C, 37, 53, generator=g) * 4
+    t = torch.randint(0, C, (3, 37, 53), generator=g)
+    zr = z.clone().requires_grad_(True)
+    seg, d, ce = O.seg_loss_multiclass(zr, t, 0.5, ignore)
+    seg.backward()
+    out, dz = ops.seg_loss_multiclass(z.to(DEV), t.to(DEV), ignore)
+    assert relerr(out[0], seg.detach()) < 1e-5 and relerr(out[1], d.detach()) < 1e-5
+    assert relerr(out[2], ce.detach()) < 1e-5
+    assert relerr(dz, zr.grad) < 1e-4
+
+
+def test_multiclass_loss_rejects_bad_input():
+    from stain2stain_amd import ops
+    z = torch.zeros(1, 3, 4, 4, device=DEV)
+    with pytest.raises(RuntimeError):                      # label 3 with 3 classes: F.one_hot raises in the reference
+        ops.seg_loss_multiclass(z, torch.full((1, 4, 4), 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.seg_loss_multiclass(z, torch.zeros(1, 4, 5, dtype=torch.long, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.seg_loss_multiclass(torch.zeros(1, 9, 4, 4, device=DEV), torch.zeros(1, 4, 4, dtype=torch.long, device=DEV))
+
+
+def test_multiclass_step_matches_golden_fp32(GM):
+    from stain2stain_amd import (FlowMatchingDecoder, MultiTaskFlowMatchingModule, SegmentationDecoder,
+                                 SharedEncoder)
+    G = GM
+    enc = SharedEncoder(3, [16, 32], precision="fp32")
+    fdec = FlowMatchingDecoder(32, [16], 3, 32, precision="fp32")
+    sdec = SegmentationDecoder(32, [16], 5, precision="fp32")
+    enc.load_state_dict(sub(G, "init/encoder."))
+    fdec.load_state_dict(sub(G, "init/flow_decoder."))
+    sdec.load_state_dict(sub(G, "init/seg_decoder."))
+    mod = MultiTaskFlowMatchingModule(enc, fdec, sdec, time_emb_dim=32, num_classes=5).to(DEV).train()
+    x0, x1, t, mask = (G[k].to(DEV) for k in ("x0", "x1", "t", "mask"))
+    _, xt, ut = mod.flow_matcher.sample_location_and_conditional_flow(x0, x1, t)
+    flow = torch.mean((mod.forward_flow(t, xt) - ut) ** 2)
+    logits = mod.forward_segmentation(x0)
+    assert relerr(logits, G["logits"]) < TOL
+    seg, d = mod.compute_segmentation_loss(logits, mask.unsqueeze(1))     # (B,1,H,W) masks are squeezed (:224-225)
+    total = flow + seg
+    total.backward()
+    for k, v in (("total", total), ("flow", flow), ("dice", d["dice"]), ("ce", d["ce"])):
+        assert relerr(v, G["loss/" + k]) < TOL, k
+    got = {}
+    for pre, m in (("encoder.", mod.encoder), ("flow_decoder.", mod.flow_decoder), ("seg_decoder.", mod.seg_decoder)):
+        got.update({pre + k: p.grad for k, p in m.named_parameters()})
+    check_grads(got, sub(G, "grad/"), TOL)
+    img, cls = mod.generate(x0[:1], num_steps=2)
+    assert cls.dtype == torch.int64 and cls.shape == (1, 1, 64, 64) and int(cls.max()) < 5

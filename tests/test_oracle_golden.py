@@ -139,3 +139,22 @@ def test_multitask_step_matches_reference():
         ref = G["after/" + k]
         assert (int(v) == int(ref)) if k.endswith("tracked") else relerr(v, ref) < FWD_TOL, k
     assert int(nb["encoder.inc.double_conv.1.num_batches_tracked"]) == 2      # the encoder ran twice
+
+
+def test_multiclass_step_matches_reference():
+    """Row f2, multiclass form: 5-class mask head, softmax Dice + cross entropy."""
+    from conftest import load_golden
+    G = load_golden("multiclass_step.npz")
+    P = sub(G, "init/")
+    losses, grads, _ = O.multitask_loss_and_grads(P, G["x0"], G["x1"], G["t"], G["mask"], 1.0, 0.5, multiclass=True)
+    for k in ("total", "flow", "dice", "ce"):
+        assert relerr(losses[k], G["loss/" + k]) < FWD_TOL, k
+    gref = sub(G, "grad/")
+    gscale = max(float(v.abs().max()) for v in gref.values())
+    for k, g in grads.items():
+        assert _grad_ok(g, gref[k], 1e-3 * gscale), k
+    z = G["lossop/z"].clone().requires_grad_(True)
+    seg, d, ce = O.seg_loss_multiclass(z, G["lossop/target"], 0.3, ignore_index=2)
+    seg.backward()
+    assert relerr(d, G["lossop/dice"]) < 1e-6 and relerr(ce, G["lossop/ce"]) < 1e-6
+    assert relerr(z.grad, G["lossop/dz"]) < 1e-5
