@@ -7,6 +7,7 @@ state_dict keys), computed by hand-written HIP kernels behind a C ABI
 from .components import FlowMatchingDecoder, FlowUNet, SegmentationDecoder, SharedEncoder, TimeEmbedding
 from .flow_matching import (ConditionalFlowMatcher, ConditionalFlowMatchingModule, MultiTaskFlowMatchingModule,
                             euler_generate)
+from . import checkpoint
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",

@@ -82,6 +82,7 @@ class CFMTrainer:
                     gv = self.flat_g[o:o + n].view(p.shape)
                     p.grad = gv
                     (self.grads_dec if owner == "dec" else self.grads_enc)[name] = gv
+        self._slot = {id(p): (offs[(owner, name)], p.numel()) for g in groups for owner, name, p in g}
         self.n_params = sum(p.numel() for g in groups for _, _, p in g)
         self.n_dec_groups = 2 + len(net.flow_decoder.ups)
         self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group)
@@ -138,6 +139,47 @@ class CFMTrainer:
         ops.adam_step_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas[0],
                        self.betas[1], self.eps, self.wd, self.bucketer.grad_scale)
         self._repack()              # master weights changed behind torch's version counter
+
+    # ------------------------------------------------------------------------------------------
+    # optimiser state in torch.optim.Adam's own layout, so a run can move between this trainer and the
+    # reference's Lightning loop (checkpoint["optimizer_states"][0], parameters in net.parameters() order)
+    def optimizer_state_dict(self) -> Dict:
+        state = {}
+        for i, p in enumerate(self.net.parameters()):
+            o, n = self._slot[id(p)]
+            if self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(self._slot)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> None:
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._slot):
+            raise ValueError("optimizer state does not match this network (one group over net.parameters() expected)")
+        if groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("amsgrad / maximize Adam states are not supported")
+        g = groups[0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        steps = set()
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        for i, p in enumerate(self.net.parameters()):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            o, n = self._slot[id(p)]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+            self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the flat Adam kernel keeps one")
+        self.step_count = steps.pop() if steps else 0
 
     def _repack(self) -> None:
         ops.pack_conv3x3_batched(self._pack_desc, self._pack_total, self._dtype)

@@ -304,6 +304,57 @@ def make_multiclass_fixture():
     print("multiclass_step.npz", {k: float(out[k]) for k in out if k.startswith("loss/")})
 
 
+def make_checkpoint_fixture():
+    """Row f3.  A Lightning-shaped checkpoint written from the reference's modules after two Adam steps of the
+    flow-matching loss (keys as a LitModule holding ``net.encoder`` / ``net.flow_decoder`` saves them, optimiser
+    state as torch.optim.Adam.state_dict() -- what Lightning stores under ``optimizer_states``), plus what the
+    reference computes after loading it: an eval-mode velocity and the parameters after a third training step."""
+    torch.manual_seed(SEED + 5)
+    feats, tdim, B, HW = (16, 32), 32, 4, 64
+    enc = SharedEncoder(3, list(feats))
+    fdec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
+    temb = TimeEmbedding(tdim)
+    params = list(enc.parameters()) + list(fdec.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(SEED + 5)
+    exp = {}
+
+    def step(tag=None):
+        x0 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+        x1 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+        t = torch.rand(B, generator=g)
+        tb = t.view(-1, 1, 1, 1)
+        xt, ut = tb * x1 + (1 - tb) * x0, x1 - x0
+        opt.zero_grad()
+        b, skips = enc(xt)
+        loss = torch.mean((fdec(b, skips, temb(t)) - ut) ** 2)
+        loss.backward()
+        opt.step()
+        if tag:
+            exp.update({tag + "/x0": npy(x0), tag + "/x1": npy(x1), tag + "/t": npy(t), tag + "/loss": npy(loss)})
+
+    enc.train(); fdec.train()
+    step(); step()
+    sd = {"net.encoder." + k: v.detach().clone() for k, v in enc.state_dict().items()}
+    sd.update({"net.flow_decoder." + k: v.detach().clone() for k, v in fdec.state_dict().items()})
+    ckpt = {"epoch": 0, "global_step": 2, "pytorch-lightning_version": "2.0.0", "state_dict": sd,
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": []}
+    torch.save(ckpt, os.path.join(OUT, "tiny_lightning.ckpt"))
+    enc.eval(); fdec.eval()
+    with torch.no_grad():
+        x = torch.rand(2, 3, HW, HW, generator=g) * 2 - 1
+        t = torch.rand(2, generator=g)
+        b, skips = enc(x)
+        exp.update({"eval/x": npy(x), "eval/t": npy(t), "eval/v": npy(fdec(b, skips, temb(t)))})
+    enc.train(); fdec.train()
+    step("resume")
+    for pre, m in (("encoder.", enc), ("flow_decoder.", fdec)):
+        for k, v in m.state_dict().items():
+            exp["resume/after/" + pre + k] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "checkpoint_expect.npz"), **exp)
+    print("tiny_lightning.ckpt + checkpoint_expect.npz", float(exp["resume/loss"]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
@@ -313,3 +364,4 @@ if __name__ == "__main__":
     make_ops_fixture()
     make_multitask_fixture()
     make_multiclass_fixture()
+    make_checkpoint_fixture()
