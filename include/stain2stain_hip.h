@@ -58,13 +58,15 @@ int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const 
                            int B, int H, int W, void* stream);
 
 /* ---- stem and head (conv_edge.hip) ----------------------------------------------------------------
- * stem: first conv of SharedEncoder.inc (shared_encoder.py:15,67), NCHW fp32 image (Cin <= 8) -> NHWC.
- * head: FlowMatchingDecoder.outc, Conv2d(k=1) to Cout <= 4 (task_decoders.py:100,132), NHWC -> NCHW fp32. */
+ * stem: first conv of SharedEncoder.inc (shared_encoder.py:15,67), NCHW fp32 image (Cin <= 6: RGB, or RGB + the
+ *       mask channel of conditional_flow_matching_conditional_mask.py:62-64) -> NHWC.
+ * head: FlowMatchingDecoder.outc / SegmentationDecoder.outc, Conv2d(k=1) to Cout <= 8 (task_decoders.py:100,132,169),
+ *       NHWC -> NCHW fp32; the fused head+loss entry point takes Cout <= 4. */
 int s2s_stem_stat_blocks(int B, int H, int W);
 int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
                          float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream);
 int s2s_stem_wgrad_blocks(int B, int H, int W);
-/* part: float[2*blocks][Cout][32]; Cin*9 <= 31; dbias may be NULL */
+/* part: float[ceil(Cin/3)][2*blocks][Cout][32]; dbias may be NULL */
 int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part, float* dw_oihw,
                            float* dbias, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
 int s2s_head_conv1x1_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float* y_nchw, int B,
@@ -166,6 +168,22 @@ int s2s_seg_loss(const float* z, const float* g, float* dz, float* out, double* 
  * work: double[(512 + 1) * 26]; 2 <= C <= 8. */
 int s2s_seg_loss_multiclass(const float* z, const long* target, float* dz, float* out, double* work, long B, long HW,
                             int C, int ignore_index, float smooth, float dice_weight, float grad_scale, void* stream);
+
+/* ---- loss variants and class conditioning (loss_variants.hip) -- SURVEY section 8 row f4 -----------------
+ * ROI-weighted MSE (conditional_flow_matching_masked.py:76-90): w = 1 + roi_lambda * mask,
+ *   out[0] = sum(w (v-u)^2) / (sum(w) + 1e-8), w broadcast over C.  v, u: float[B][C][HW]; mask: float[B][HW];
+ *   dv optional; work: double[512*2 + 2].
+ * ROI Charbonnier (conditional_flow_matching_ROI_loss.py:78-95): out[0] = sum(sqrt((p-t)^2 + eps_charb^2) * mask)
+ *   / (sum(mask) * C + eps_area); value only (its inputs are data).
+ * Class conditioning (class_conditional_flow_matching.py:39-71, build-defined network side): out = temb + table[y]. */
+int s2s_weighted_mse(const float* v, const float* u, const float* mask, float* dv, float* out, double* work, long B,
+                     int C, long HW, float roi_lambda, float grad_scale, void* stream);
+int s2s_charbonnier_roi(const float* pred, const float* truth, const float* mask, float* out, double* work, long B,
+                        int C, long HW, float eps_charb, float eps_area, void* stream);
+int s2s_class_embed_add(const float* temb, const float* table, const long* y, float* out, int B, int dim,
+                        void* stream);
+int s2s_class_embed_bwd(const float* dout, const long* y, float* dtable, int accumulate, int B, int dim,
+                        int num_classes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,11 @@ Reference lines each function follows (relative to the reference checkout):
                           src/models/conditional_flow_matching_multitask.py:36-53, :119, :174-202
 * ``multiclass_dice_loss`` / ``seg_loss_multiclass``
                           src/models/conditional_flow_matching_multitask_multiclassloss.py:41-83, :159, :214-245
+* ``weighted_mse``        src/models/conditional_flow_matching_masked.py:76-90
+* ``charbonnier_roi``     src/models/conditional_flow_matching_ROI_loss.py:78-95
+* ``variant_loss_and_grads``  mask as 4th input channel (conditional_flow_matching_conditional_mask.py:62-64,
+                          :73-82), optional ROI weighting of the loss, optional class row added to the time
+                          embedding (build-defined stand-in for the absent third-party class-conditional U-Net)
 * ``multitask_loss_and_grads``  :204-257 (flow term on xt, mask head on the source image,
                           total = flow + seg_loss_weight * seg; the encoder runs twice, so its
                           BatchNorm running statistics advance twice per step)
@@ -252,6 +257,39 @@ def seg_loss_multiclass(logits: Tensor, target: Tensor, dice_weight: float = 0.5
     d = multiclass_dice_loss(logits, target, logits.shape[1], smooth, ignore_index)
     ce = F.cross_entropy(logits, target, ignore_index=ignore_index)
     return dice_weight * d + (1 - dice_weight) * ce, d, ce
+
+
+def weighted_mse(v: Tensor, u: Tensor, mask: Tensor, lam: float = 10.0) -> Tensor:
+    w = (1.0 + lam * mask.float()).expand_as(v)
+    return (w * (v - u) ** 2).sum() / (w.sum() + 1e-8)
+
+
+def charbonnier_roi(pred: Tensor, truth: Tensor, mask: Tensor, eps_charb: float = 1e-3,
+                    eps_area: float = 1e-8) -> Tensor:
+    m = mask.float()
+    d = pred - truth
+    return (torch.sqrt(d * d + eps_charb * eps_charb) * m).sum() / (m.sum() * pred.shape[1] + eps_area)
+
+
+def variant_loss_and_grads(P: Params, x0: Tensor, x1: Tensor, t: Tensor, mask: Optional[Tensor] = None,
+                           mask_as_channel: bool = False, roi_lambda: Optional[float] = None,
+                           y: Optional[Tensor] = None):
+    """Training-mode step of the loss / conditioning variants.  Returns (loss, v, grads, new_buffers)."""
+    keys = trainable_keys(P)
+    Q = dict(P)
+    for k in keys:
+        Q[k] = P[k].detach().clone().requires_grad_(True)
+    nb: Params = {}
+    xt, ut = cfm_sample(x0, x1, t)
+    xin = torch.cat([xt, mask.float()], dim=1) if mask_as_channel else xt
+    temb = time_embedding(t, Q["flow_decoder.time_mlp.0.weight"].shape[1])
+    if y is not None:
+        temb = temb + Q["label_emb.weight"][y.long()]
+    b, skips = encoder_forward(xin, Q, True, nb)
+    v = decoder_forward(b, skips, temb, Q, True, nb)
+    loss = weighted_mse(v, ut, mask, roi_lambda) if roi_lambda is not None else cfm_loss(v, ut)
+    gs = torch.autograd.grad(loss, [Q[k] for k in keys])
+    return loss.detach(), v.detach(), dict(zip(keys, gs)), nb
 
 
 def multitask_loss_and_grads(P: Params, x0: Tensor, x1: Tensor, t: Tensor, mask: Tensor,

@@ -4,12 +4,17 @@ Drop-in replacements for the reference's torch-only network components (same sig
 state_dict keys), computed by hand-written HIP kernels behind a C ABI
 (include/stain2stain_hip.h, stain2stain_amd/csrc/*.hip).  HIP only: there is no CPU fallback.
 """
-from .components import FlowMatchingDecoder, FlowUNet, SegmentationDecoder, SharedEncoder, TimeEmbedding
-from .flow_matching import (ConditionalFlowMatcher, ConditionalFlowMatchingModule, MultiTaskFlowMatchingModule,
-                            euler_generate)
+from .components import (ClassConditionalFlowUNet, FlowMatchingDecoder, FlowUNet, SegmentationDecoder, SharedEncoder,
+                         TimeEmbedding)
+from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowMatcher,
+                            ConditionalFlowMatchingModule, MaskConditionedFlowMatchingModule,
+                            MultiTaskFlowMatchingModule, ROICharbonnierFlowMatchingModule,
+                            ROIWeightedFlowMatchingModule, euler_generate)
 from . import checkpoint
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
            "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate",
-           "CFMTrainer"]
+           "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
+           "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
+           "checkpoint"]

@@ -133,8 +133,8 @@ class SharedEncoder(nn.Module):
             features = [64, 128, 256, 512, 1024]
         features = list(features)
         _check_channels(features)
-        if in_channels > 3:
-            raise ValueError("stain2stain_amd stem kernels support at most 3 input channels (RGB tiles)")
+        if in_channels > 6:
+            raise ValueError("stain2stain_amd stem kernels support at most 6 input channels (RGB tiles + condition)")
         self.in_channels = in_channels
         self.features = features
         self.return_skip_connections = return_skip_connections
@@ -302,3 +302,49 @@ class FlowUNet(nn.Module):
             t = t.expand(x.shape[0])
         bottleneck, skips = self.encoder(x)
         return self.flow_decoder(bottleneck, skips, self.time_embedding(t))
+
+
+class _ClassEmbedAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, temb: torch.Tensor, table: torch.Tensor, y: torch.Tensor):
+        ctx.save_for_backward(y)
+        ctx.num_classes = table.shape[0]
+        return ops.class_embed_add(temb.detach().float(), table.detach(), y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        return None, ops.class_embed_bwd(dout.float(), y, ctx.num_classes), None
+
+
+class ClassConditionalFlowUNet(FlowUNet):
+    """``net(t, x, y) -> v`` for ClassConditionalFlowMatchingLitModule (class_conditional_flow_matching.py:39-47,
+    configs/model/class_conditional_flow_matching.yaml:19-22 ``num_classes: 3``).  The reference's network there is
+    the third-party torchcfm UNetModel (absent); this is the in-repo U-Net with a learned ``label_emb`` row added
+    to the sinusoidal time embedding -- build-defined, parity unpinned (SURVEY section 8 d cfg5 / f4).  With
+    ``y=None`` it is the unconditional FlowUNet."""
+
+    def __init__(self, in_channels: int = 3, features: Optional[List[int]] = None, out_channels: int = 3,
+                 time_emb_dim: int = 256, num_classes: int = 3, precision: str = "bf16"):
+        super().__init__(in_channels, features, out_channels, time_emb_dim, precision)
+        self.num_classes = num_classes
+        self.label_emb = nn.Embedding(num_classes, time_emb_dim)
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor, y: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        if t.dim() == 0:
+            t = t.unsqueeze(0).expand(x.shape[0])
+        elif t.dim() == 1 and t.shape[0] == 1:
+            t = t.expand(x.shape[0])
+        temb = self.time_embedding(t)
+        if y is not None:
+            y = y.to(torch.int64).reshape(-1)
+            if y.shape[0] == 1 and x.shape[0] > 1:
+                y = y.expand(x.shape[0])
+            y = y.contiguous()
+            if y.shape[0] != x.shape[0]:
+                raise ValueError(f"y has {y.shape[0]} labels for a batch of {x.shape[0]}")
+            if int(y.min()) < 0 or int(y.max()) >= self.num_classes:      # nn.Embedding raises IndexError here
+                raise IndexError(f"class label outside [0, {self.num_classes})")
+            temb = _ClassEmbedAdd.apply(temb, self.label_emb.weight, y)
+        bottleneck, skips = self.encoder(x)
+        return self.flow_decoder(bottleneck, skips, temb)

@@ -920,7 +920,7 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
 }
 
 // =========================================================================================================
-// stem: Conv3x3(pad 1) from the NCHW fp32 image (Cin*9 <= 32) on the same MFMA path.  The im2col patch of a
+// stem: Conv3x3(pad 1) from the NCHW fp32 image (Cin <= 6, three channels per K = 32 step) on the same MFMA path.  The im2col patch of a
 // 16x16 pixel tile is built in LDS as a [256][32] image (k = ci*9 + tap), the weights as [BN][32]; one
 // K = 32 step per 32x32 block, then the common epilogue (bias, BatchNorm partial sums, coalesced NHWC store).
 // The layer is bound by writing its output; T = float uses the three-way bf16 split like the main kernels.
@@ -944,11 +944,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(Conv3x3Args a, const flo
   const int ty = bt % a.tilesY;
   const int img = bt / a.tilesY;
   const int y0 = ty * TH, x0p = tx * TW, n0 = blockIdx.y * BN;
-  const int K = Cin * 9;
-  for (int i = tid; i < Cin * 324; i += 256) {
+  const int Kall = Cin * 9;
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+  // input channels in groups of three (27 of the 32 k-columns); RGB is one pass, RGB + mask channel two
+  for (int c0 = 0; c0 < Cin; c0 += 3) {
+  const int nc = (Cin - c0) < 3 ? (Cin - c0) : 3, K = nc * 9;
+  for (int i = tid; i < nc * 324; i += 256) {
     const int ci = i / 324, rr = i - ci * 324, hy = rr / 18, hx = rr - hy * 18;
     const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-    xl[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? x[(((long)img * Cin + ci) * a.H + gy) * a.W + gx] : 0.f;
+    xl[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                ? x[(((long)img * Cin + c0 + ci) * a.H + gy) * a.W + gx] : 0.f;
   }
   for (int i = tid; i < BN * 4; i += 256) {          // weight rows, 8 k per piece
     const int n = i >> 2, pc = i & 3;
@@ -956,7 +967,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(Conv3x3Args a, const flo
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int kk = pc * 8 + k;
-      const float v = (n0 + n < a.Cout && kk < K) ? w[(long)(n0 + n) * K + kk] : 0.f;
+      const float v = (n0 + n < a.Cout && kk < K) ? w[(long)(n0 + n) * Kall + c0 * 9 + kk] : 0.f;
       if (k < 4) pw.a[k] = v; else pw.b[k - 4] = v;
     }
     if constexpr (SPLIT) pw.to_lds(ldsW, W_BYTES, n * ROWB + pc * 16);
@@ -993,13 +1004,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(Conv3x3Args a, const flo
     }
   }
   __syncthreads();
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     bf16x8 af[NIMG][MI], bfr[NIMG][NI];
@@ -1027,6 +1031,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(Conv3x3Args a, const flo
       }
   }
   __syncthreads();
+  }   // channel groups
   conv_epilogue<T, TH, TW, BN, WM, WN, LDS_MAIN>(a, acc, smem, img, y0, x0p, n0);
 }
 

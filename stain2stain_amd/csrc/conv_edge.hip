@@ -1,6 +1,6 @@
 // The two bandwidth-bound convolutions at the ends of the U-Net.
 //
-//   * stem: Conv3x3(pad 1) from the image tensor (NCHW fp32, Cin <= 3) to NHWC features -- the first conv of
+//   * stem: Conv3x3(pad 1) from the image tensor (NCHW fp32, Cin <= 6: RGB, or RGB + mask channel) to NHWC features -- the first conv of
 //     SharedEncoder.inc (src/models/components/shared_encoder.py:15,67).  Forward: one K = 32 MFMA step on an
 //     im2col patch built in LDS (kernel in conv3x3_mfma.hip, next to the shared epilogue); weight/bias gradient:
 //     the MFMA kernel below.  The layer is bound by moving its 64-channel output / gradient.
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave & 1, whalf = wave >> 1;
   const int co0 = blockIdx.y * 64;
-  const int K = Cin * 9;
+  const int c0 = blockIdx.z * 3;                             // channel group (27 of 32 k-columns, +1 for the bias)
+  const int nc = (Cin - c0) < 3 ? (Cin - c0) : 3, K = nc * 9;
   const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
   const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + pq * 4) * 2;
   const int ntiles = B * tilesY * tilesX;
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
     const int n = bt / tilesY;
     const int y0 = ty * 16, x0 = tx * 16;
     __syncthreads();   // previous tile fully consumed
-    for (int i = tid; i < Cin * 324; i += 256) {
+    for (int i = tid; i < nc * 324; i += 256) {
       const int ci = i / 324, r = i - ci * 324, hy = r / 18, hx = r - hy * 18;
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      xl[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((long)n * Cin + ci) * H + gy) * W + gx] : 0.f;
+      xl[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((long)n * Cin + c0 + ci) * H + gy) * W + gx] : 0.f;
     }
     // dY tile: 256 px x 64 co = 2048 pieces of 8 channels
 #pragma unroll
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
           if (kk < K) {
             const int ci = kk / 9, t = kk - ci * 9;
             v = xl[ci * 324 + (py + t / 3) * 18 + px + t % 3];
-          } else if (kk == K) {
+          } else if (kk == K && c0 == 0) {
             v = inside ? 1.f : 0.f;   // dY is zero outside anyway
           }
           v8[k] = v;
@@ -149,16 +150,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-    if (co < Cout) part[(((long)blockIdx.x * 2 + whalf) * Cout + co) * 32 + kcol] = acc[j];
+    if (co < Cout)
+      part[((((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 + whalf) * Cout + co) * 32 + kcol] = acc[j];
   }
 }
 
-// one workgroup per output channel: 32 k-columns x 8 slab groups
+// one workgroup per (output channel, channel group): 32 k-columns x 8 slab groups
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
                                          int accumulate) {
   __shared__ double red[8][33];
-  const int K = Cin * 9;
+  const int c0 = blockIdx.y * 3;
+  const int K = ((Cin - c0) < 3 ? (Cin - c0) : 3) * 9;
   const int co = blockIdx.x, k = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  part += (long)blockIdx.y * nslab * Cout * 32;
   double s = 0.0;
   for (int b = sg; b < nslab; b += 8) s += (double)part[((long)b * Cout + co) * 32 + k];
   red[sg][k] = s;
@@ -166,9 +170,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* par
   if (sg == 0) {
     for (int j = 1; j < 8; ++j) s += red[j][k];
     if (k < K) {
-      float* dst = dw + co * K + k;
+      float* dst = dw + co * Cin * 9 + c0 * 9 + k;
       *dst = accumulate ? *dst + (float)s : (float)s;
-    } else if (k == K && db) {
+    } else if (k == K && c0 == 0 && db) {
       db[co] = accumulate ? db[co] + (float)s : (float)s;
     }
   }
@@ -439,7 +443,7 @@ extern "C" int s2s_stem_stat_blocks(int B, int H, int W) {
 extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y,
                                     int ldy, float* stat_part, int B, int H, int W, int Cin, int Cout, void* stream) {
   if (!x_nchw || !w_oihw || !y) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin * 9 > 32 || Cout <= 0 || (Cout % 8) || (ldy % 8))
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 6 || Cout <= 0 || (Cout % 8) || (ldy % 8))
     return S2S_ERR_SHAPE;
   return s2s_internal_stem_fwd(dtype, x_nchw, w_oihw, bias, y, ldy, stat_part, B, H, W, Cin, Cout,
                                (hipStream_t)stream);
@@ -451,22 +455,22 @@ extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
   return nt < 256 ? nt : 256;
 }
 
-// part: float[2*blocks][Cout][32]
+// part: float[ceil(Cin/3)][2*blocks][Cout][32]
 extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const float* x_nchw, float* part,
                                       float* dw_oihw, float* dbias, int accumulate, int B, int H, int W, int Cin,
                                       int Cout, void* stream) {
   if (!dy || !x_nchw || !part || !dw_oihw) return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin * 9 > 31 || Cout <= 0 || (Cout % 8) || (lddy % 8))
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 6 || Cout <= 0 || (Cout % 8) || (lddy % 8))
     return S2S_ERR_SHAPE;
   const int nb = s2s_stem_wgrad_blocks(B, H, W);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(nb, cdiv(Cout, 64));
+  dim3 grid(nb, cdiv(Cout, 64), cdiv(Cin, 3));
   if (dtype == S2S_BF16) {
-    const int lds = 1 * (2 * 256 * 64 + 256 * 64) + Cin * 324 * 4;
+    const int lds = 1 * (2 * 256 * 64 + 256 * 64) + 3 * 324 * 4;
     hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, lddy, x_nchw, part, B,
                        H, W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else if (dtype == S2S_F32) {
-    const int lds = 3 * (2 * 256 * 64 + 256 * 64) + Cin * 324 * 4;
+    const int lds = 3 * (2 * 256 * 64 + 256 * 64) + 3 * 324 * 4;
     static bool attr_done = false;
     if (!attr_done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<float>),
@@ -477,7 +481,7 @@ extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, lddy, x_nchw, part, B, H,
                        W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else return S2S_ERR_DTYPE;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout), dim3(256), 0, s, part, 2 * nb, Cout, Cin, dw_oihw, dbias,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout, cdiv(Cin, 3)), dim3(256), 0, s, part, 2 * nb, Cout, Cin, dw_oihw, dbias,
                      accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;

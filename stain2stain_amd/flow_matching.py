@@ -122,6 +122,122 @@ class ConditionalFlowMatchingModule(_Base):
         return euler_generate(self.net, source_img, num_steps)
 
 
+class _WeightedMSE(torch.autograd.Function):
+    """sum(w (v-u)^2) / (sum(w) + 1e-8), w = 1 + lam * mask, with the fused loss/gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, v: torch.Tensor, u: torch.Tensor, mask: torch.Tensor, lam: float):
+        loss, dv = ops.weighted_mse(v.detach().float(), u.detach().float(), mask.detach(), lam, want_grad=True)
+        ctx.save_for_backward(dv)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dv,) = ctx.saved_tensors
+        return dv * gloss, None, None, None
+
+
+class ROIWeightedFlowMatchingModule(ConditionalFlowMatchingModule):
+    """conditional_flow_matching_masked.py:60-91 -- batches are (source, target, mask); pixels inside the mask
+    count ``1 + roi_lambda`` times in the flow-matching MSE (``roi_lambda`` attribute, default 10 as :78)."""
+
+    roi_lambda: float = 10.0
+
+    def model_step(self, batch) -> torch.Tensor:
+        x0, x1, mask = batch
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(x0, x1)
+        return _WeightedMSE.apply(self.forward(t, xt), ut, mask, float(getattr(self, "roi_lambda", 10.0)))
+
+
+class ROICharbonnierFlowMatchingModule(ConditionalFlowMatchingModule):
+    """conditional_flow_matching_ROI_loss.py:64-97 -- flow-matching MSE plus ``lambda_roi`` times the Charbonnier
+    distance between xt and x1 inside the mask (a data-only term: it shifts the logged loss, not the gradients)."""
+
+    lambda_roi: float = 1.0
+
+    def model_step(self, batch) -> torch.Tensor:
+        x0, x1, mask = batch
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(x0, x1)
+        loss_fm = _MSE.apply(self.forward(t, xt), ut)
+        roi = ops.charbonnier_roi(xt, x1.float(), mask, 1e-3, 1e-8)[0]
+        return loss_fm + float(getattr(self, "lambda_roi", 1.0)) * roi
+
+
+class MaskConditionedFlowMatchingModule(ConditionalFlowMatchingModule):
+    """conditional_flow_matching_conditional_mask.py:54-82 (``mask_toggle=False``) and
+    conditional_flow_matching_conditional_toggle_mask.py:54-103 (``mask_toggle=True``: the training step zeroes the
+    mask with probability 1/2, drawn with ``torch.rand(1).item()`` like the reference).  The mask is the fourth
+    input channel of ``net`` (``in_channels: 4``)."""
+
+    def __init__(self, *args, mask_toggle: bool = False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.mask_toggle = mask_toggle
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        return self.net(t, torch.cat([x, mask.to(x.dtype)], dim=1))
+
+    def model_step(self, batch, use_mask_toggle: bool = False) -> torch.Tensor:
+        x0, x1, mask = batch
+        if use_mask_toggle and torch.rand(1).item() < 0.5:
+            mask = torch.zeros_like(mask)
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(x0, x1)
+        return _MSE.apply(self.forward(t, xt, mask), ut)
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        loss = self.model_step(batch, use_mask_toggle=self.mask_toggle)
+        self.log("train/loss", loss, on_step=True, on_epoch=True, prog_bar=True, sync_dist=True)
+        return loss
+
+    @torch.no_grad()
+    def generate(self, source_img: torch.Tensor, mask: torch.Tensor, num_steps: int = 100) -> torch.Tensor:
+        if source_img.dim() == 3:
+            source_img, mask = source_img.unsqueeze(0), mask.unsqueeze(0)
+        outer = self
+
+        class _Net(torch.nn.Module):
+            def forward(s, t, x):
+                return outer.forward(t, x, mask)
+
+        was = self.net.training
+        self.net.eval()
+        out = euler_generate(_Net(), source_img, num_steps)
+        self.net.train(was)
+        return out
+
+
+class ClassConditionalFlowMatchingModule(ConditionalFlowMatchingModule):
+    """class_conditional_flow_matching.py:39-71,130-190 -- batches are (source, target, target_label); the label
+    conditions the network call ``net(t, x, y=y)``; ``generate(source, target_class, num_steps)``."""
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        return self.net(t, x, y=y)
+
+    def model_step(self, batch) -> torch.Tensor:
+        x0, x1, label = batch
+        t, xt, ut = self.flow_matcher.sample_location_and_conditional_flow(x0, x1)
+        return _MSE.apply(self.forward(t, xt, label.long()), ut)
+
+    @torch.no_grad()
+    def generate(self, source_img: torch.Tensor, target_class, num_steps: int = 100) -> torch.Tensor:
+        if source_img.dim() == 3:
+            source_img = source_img.unsqueeze(0)
+        B, dev = source_img.shape[0], source_img.device
+        y = (torch.tensor([target_class] * B, device=dev) if isinstance(target_class, int)
+             else target_class.to(dev))
+        outer = self
+
+        class _Net(torch.nn.Module):
+            def forward(s, t, x):
+                yy = y.expand(x.shape[0]) if y.dim() == 0 else y[:x.shape[0]]
+                return outer.net(t, x, y=yy)
+
+        was = self.net.training
+        self.net.eval()
+        out = euler_generate(_Net(), source_img, num_steps)
+        self.net.train(was)
+        return out
+
+
 class _SegLoss(torch.autograd.Function):
     """dw * Dice(sigmoid(z), g) + (1-dw) * BCEWithLogits(z, g) with the fused two-pass kernel."""
 

@@ -197,7 +197,7 @@ def stem_wgrad(dy: torch.Tensor, x_nchw: torch.Tensor, dw: torch.Tensor, dbias: 
     cin = x_nchw.shape[1]
     pdy, lddy = _nhwc(dy)
     nb = _L().s2s_stem_wgrad_blocks(B, H, W)
-    part = torch.empty((2 * nb, cout, 32), dtype=torch.float32, device=dy.device)
+    part = torch.empty(((cin + 2) // 3, 2 * nb, cout, 32), dtype=torch.float32, device=dy.device)
     rc = _L().s2s_stem_conv3x3_wgrad(_dt(dy), pdy, lddy, _f32(x_nchw), _f32(part), _f32(dw), _f32(dbias),
                                      int(accumulate), B, H, W, cin, cout, _stream())
     _native.check(rc, "stem_conv3x3_wgrad")
@@ -460,6 +460,62 @@ def seg_loss_multiclass(z: torch.Tensor, target: torch.Tensor, ignore_index: int
                                                H * W, C, int(ignore_index), float(smooth), float(dice_weight),
                                                float(grad_scale), _stream()), "seg_loss_multiclass")
     return out, dz
+
+
+def _mask_bhw(mask: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    B, C, H, W = like.shape
+    if mask.dim() == 4 and mask.shape[1] == 1:
+        mask = mask[:, 0]
+    if tuple(mask.shape) != (B, H, W):
+        raise RuntimeError(f"stain2stain_amd: mask shape {tuple(mask.shape)} does not match images {tuple(like.shape)}")
+    return mask.to(torch.float32).contiguous()
+
+
+def weighted_mse(v: torch.Tensor, u: torch.Tensor, mask: torch.Tensor, roi_lambda: float = 10.0,
+                 want_grad: bool = True, grad_scale: float = 1.0):
+    """sum(w (v-u)^2) / (sum(w) + 1e-8) with w = 1 + roi_lambda * mask broadcast over channels; (loss[1], dv)."""
+    if v.dim() != 4 or v.shape != u.shape:
+        raise RuntimeError("stain2stain_amd: weighted_mse wants v, u of equal shape [B,C,H,W]")
+    B, C, H, W = v.shape
+    v, u, m = v.contiguous(), u.contiguous(), _mask_bhw(mask, v)
+    out = torch.empty((1,), dtype=torch.float32, device=v.device)
+    dv = torch.empty_like(v) if want_grad else None
+    work = torch.empty((512 * 2 + 2,), dtype=torch.float64, device=v.device)
+    _native.check(_L().s2s_weighted_mse(_f32(v), _f32(u), _f32(m), _f32(dv), _f32(out), work.data_ptr(), B, C, H * W,
+                                        float(roi_lambda), float(grad_scale), _stream()), "weighted_mse")
+    return out, dv
+
+
+def charbonnier_roi(pred: torch.Tensor, truth: torch.Tensor, mask: torch.Tensor, eps_charb: float = 1e-3,
+                    eps_area: float = 1e-8) -> torch.Tensor:
+    """sum(sqrt((pred-truth)^2 + eps_charb^2) * mask) / (sum(mask) * C + eps_area); value only."""
+    if pred.dim() != 4 or pred.shape != truth.shape:
+        raise RuntimeError("stain2stain_amd: charbonnier_roi wants pred, truth of equal shape [B,C,H,W]")
+    B, C, H, W = pred.shape
+    pred, truth, m = pred.contiguous(), truth.contiguous(), _mask_bhw(mask, pred)
+    out = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    work = torch.empty((512 * 2 + 2,), dtype=torch.float64, device=pred.device)
+    _native.check(_L().s2s_charbonnier_roi(_f32(pred), _f32(truth), _f32(m), _f32(out), work.data_ptr(), B, C, H * W,
+                                           float(eps_charb), float(eps_area), _stream()), "charbonnier_roi")
+    return out
+
+
+def class_embed_add(temb: torch.Tensor, table: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    B, dim = temb.shape
+    if table.shape[1] != dim or y.shape != (B,):
+        raise RuntimeError("stain2stain_amd: class_embed_add shape mismatch")
+    out = torch.empty_like(temb)
+    _native.check(_L().s2s_class_embed_add(_f32(temb.contiguous()), _f32(table), y.data_ptr(), _f32(out), B, dim,
+                                           _stream()), "class_embed_add")
+    return out
+
+
+def class_embed_bwd(dout: torch.Tensor, y: torch.Tensor, num_classes: int) -> torch.Tensor:
+    B, dim = dout.shape
+    dtable = torch.empty((num_classes, dim), dtype=torch.float32, device=dout.device)
+    _native.check(_L().s2s_class_embed_bwd(_f32(dout.contiguous()), y.data_ptr(), _f32(dtable), 0, B, dim,
+                                           num_classes, _stream()), "class_embed_bwd")
+    return dtable
 
 
 def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:

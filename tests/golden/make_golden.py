@@ -355,6 +355,78 @@ def make_checkpoint_fixture():
     print("tiny_lightning.ckpt + checkpoint_expect.npz", float(exp["resume/loss"]))
 
 
+def make_variants_fixture():
+    """Row f4.  Network: the reference's SharedEncoder(in_channels=4) + FlowMatchingDecoder, fed cat([xt, mask]) as
+    ConditionalFlowMatchingLitModule.forward does (conditional_flow_matching_conditional_mask.py:62-64).  Losses
+    driven from here with stock torch ops (their modules import lightning / torchcfm): plain MSE (:82), the
+    ROI-weighted MSE (conditional_flow_matching_masked.py:76-90) and the Charbonnier ROI value
+    (conditional_flow_matching_ROI_loss.py:78-95).  Seed chosen like the multiclass fixture's."""
+    feats, tdim, B, HW = (16, 32), 32, 4, 64
+
+    def run(seed, dtype, jitter=0):
+        torch.manual_seed(seed)
+        enc = SharedEncoder(4, list(feats))
+        fdec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
+        temb = TimeEmbedding(tdim)
+        g = torch.Generator().manual_seed(seed)
+        out = {}
+        mods = (("encoder.", enc), ("flow_decoder.", fdec))
+        for pre, m in mods:
+            for k, v in m.state_dict().items():
+                out["init/" + pre + k] = npy(v)
+        x0 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+        x1 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+        t = torch.rand(B, generator=g)
+        mask = (torch.rand(B, 1, HW // 8, HW // 8, generator=g) > 0.6).float()
+        mask = mask.repeat_interleave(8, 2).repeat_interleave(8, 3)            # blocky ROI, like a tissue mask
+        out.update({"x0": npy(x0), "x1": npy(x1), "t": npy(t), "mask": npy(mask)})
+        x0, x1, t, mk = x0.to(dtype), x1.to(dtype), t.to(dtype), mask.to(dtype)
+        if jitter:
+            gj = torch.Generator().manual_seed(jitter)
+            x0 = x0 + 3e-7 * torch.randn(x0.shape, generator=gj, dtype=dtype)
+            x1 = x1 + 3e-7 * torch.randn(x1.shape, generator=gj, dtype=dtype)
+        for m in (enc, fdec):
+            m.train().to(dtype)
+        tb = t.view(-1, 1, 1, 1)
+        xt, ut = tb * x1 + (1 - tb) * x0, x1 - x0
+        for tag in ("mse", "roi"):
+            for m in (enc, fdec):
+                m.zero_grad()
+            b, skips = enc(torch.cat([xt, mk], dim=1))
+            vt = fdec(b, skips, temb(t).to(dtype))
+            if tag == "mse":
+                loss = torch.mean((vt - ut) ** 2)
+            else:
+                w = (1.0 + 10.0 * mk).expand_as(vt)
+                loss = (w * (vt - ut) ** 2).sum() / (w.sum() + 1e-8)
+            loss.backward()
+            out.update({tag + "/loss": npy(loss), tag + "/v": npy(vt)})
+            for pre, m in mods:
+                for k, prm in m.named_parameters():
+                    out[tag + "/grad/" + pre + k] = npy(prm.grad)
+        d = xt - x1
+        charb = torch.sqrt(d * d + 1e-3 * 1e-3)
+        out["charb/value"] = npy((charb * mk).sum() / (mk.sum() * 3 + 1e-8))
+        return out
+
+    for seed in range(SEED + 6, SEED + 60):
+        out, ref64 = run(seed, torch.float32), run(seed, torch.float64)
+        gkeys = [k for k in out if "/grad/" in k]
+        gs = max(float(np.abs(out[k]).max()) for k in gkeys)
+        worst = 0.0
+        for other in [out] + [run(seed, torch.float64, j) for j in (1, 2, 3, 4)]:
+            worst = max(worst, max(float(np.abs(other[k] - ref64[k]).max())
+                                   / max(float(np.abs(ref64[k]).max()), 1e-3 * gs) for k in gkeys))
+        print(f"  seed {seed}: reference gradients under fp32/fp64/jitter move by {worst:.2e}")
+        if worst < 2e-4:
+            break
+    else:
+        raise RuntimeError("no well-conditioned seed found")
+    out["meta/seed"] = np.int64(seed)
+    np.savez_compressed(os.path.join(OUT, "variants_step.npz"), **out)
+    print("variants_step.npz", {k: float(out[k]) for k in ("mse/loss", "roi/loss", "charb/value")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
@@ -365,3 +437,4 @@ if __name__ == "__main__":
     make_multitask_fixture()
     make_multiclass_fixture()
     make_checkpoint_fixture()
+    make_variants_fixture()

@@ -119,11 +119,14 @@ def test_conv3x3_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_stem_and_head(dtype):
+@pytest.mark.parametrize("cin,hc", [(3, 3), (1, 1), (4, 5), (6, 8)])
+def test_stem_and_head(dtype, cin, hc):
+    """cin 4 = RGB + mask channel (conditional_flow_matching_conditional_mask.py:62-64); hc = head channels
+    (3 RGB velocity, 1 mask logit, num_classes logits)."""
     from stain2stain_amd import ops
     g = torch.Generator().manual_seed(11)
-    x = torch.rand(2, 3, 21, 30, generator=g) * 2 - 1
-    w = (torch.rand(16, 3, 3, 3, generator=g) * 2 - 1) * 0.3
+    x = torch.rand(2, cin, 21, 30, generator=g) * 2 - 1
+    w = (torch.rand(16, cin, 3, 3, generator=g) * 2 - 1) * 0.3
     b = torch.rand(16, generator=g) - 0.5
     ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1)   # bf16 mode stages image patch and weights in bf16
     y, stat = ops.stem_fwd(x.to(DEV), w.to(DEV), b.to(DEV), dtype)
@@ -137,23 +140,23 @@ def test_stem_and_head(dtype):
     bv = b.clone().requires_grad_(True)
     # the MFMA stem weight-gradient stages the image patch in the compute dtype (bf16 mode rounds it)
     (F.conv2d(rnd(x, dtype), wv, bv, padding=1) * rnd(dy, dtype)).sum().backward()
-    dw = torch.empty(16, 3, 3, 3, device=DEV)
+    dw = torch.empty(16, cin, 3, 3, device=DEV)
     db = torch.empty(16, device=DEV)
     ops.stem_wgrad(nhwc(dy, dtype), x.to(DEV), dw, db)
     assert relerr(dw.cpu(), wv.grad) < 1e-4
     assert relerr(db.cpu(), bv.grad) < 1e-4
     # head 1x1
     a = torch.rand(2, 16, 21, 30, generator=g) * 2 - 1
-    hw = ((torch.rand(3, 16, 1, 1, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
-    hb = (torch.rand(3, generator=g) - 0.5).requires_grad_(True)
+    hw = ((torch.rand(hc, 16, 1, 1, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    hb = (torch.rand(hc, generator=g) - 0.5).requires_grad_(True)
     av = rnd(a, dtype).requires_grad_(True)
     out = F.conv2d(av, hw, hb)
     v = ops.head_fwd(nhwc(a, dtype), hw.detach().to(DEV), hb.detach().to(DEV))
     assert relerr(v.cpu(), out) < 1e-5
     dv = torch.rand(out.shape, generator=g) - 0.5
     (out * dv).sum().backward()
-    dw = torch.empty(3, 16, 1, 1, device=DEV)
-    db = torch.empty(3, device=DEV)
+    dw = torch.empty(hc, 16, 1, 1, device=DEV)
+    db = torch.empty(hc, device=DEV)
     dx = ops.head_bwd(dv.to(DEV), nhwc(a, dtype), hw.detach().to(DEV), dw, db)
     assert relerr(nchw(dx), av.grad) < tol_act(dtype)
     assert relerr(dw.cpu(), hw.grad) < 1e-4

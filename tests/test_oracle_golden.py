@@ -158,3 +158,20 @@ def test_multiclass_step_matches_reference():
     seg.backward()
     assert relerr(d, G["lossop/dice"]) < 1e-6 and relerr(ce, G["lossop/ce"]) < 1e-6
     assert relerr(z.grad, G["lossop/dz"]) < 1e-5
+
+
+def test_loss_and_conditioning_variants_match_reference():
+    """Row f4: mask as 4th input channel, ROI-weighted MSE, Charbonnier ROI value."""
+    from conftest import load_golden
+    G = load_golden("variants_step.npz")
+    P = sub(G, "init/")
+    for tag, lam in (("mse", None), ("roi", 10.0)):
+        loss, v, grads, _ = O.variant_loss_and_grads(P, G["x0"], G["x1"], G["t"], G["mask"], mask_as_channel=True,
+                                                     roi_lambda=lam)
+        assert relerr(loss, G[tag + "/loss"]) < FWD_TOL and relerr(v, G[tag + "/v"]) < FWD_TOL
+        gref = sub(G, tag + "/grad/")
+        gscale = max(float(x.abs().max()) for x in gref.values())
+        for k, g in grads.items():
+            assert _grad_ok(g, gref[k], 1e-3 * gscale), (tag, k)
+    xt, _ = O.cfm_sample(G["x0"], G["x1"], G["t"])
+    assert relerr(O.charbonnier_roi(xt, G["x1"], G["mask"]), G["charb/value"]) < 1e-6
