@@ -27,6 +27,8 @@ def timeit(fn, n=10):
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
+if os.environ.get("LAYERS"):
+    FWD = [FWD[int(i)] for i in os.environ["LAYERS"].split(",")]
 for (H, c0, c1, cout) in FWD:
     cin = c0 + c1
     x = ((torch.rand(B, H, H, cin, device=dev) * 2 - 1) * float(os.environ.get("ZERO", "1") != "0")).to(dt)
@@ -49,6 +51,15 @@ for (H, c0, c1, cout) in FWD:
     if which in ("all", "wgrad"):
         t = timeit(lambda: ops.conv3x3_wgrad(dy, x0, x1, grad))
         row += f" wgrad {t*1e3:7.1f} us {gflop/t:7.0f} TF"; tot["wgrad"][0] += gflop; tot["wgrad"][1] += t
+    if which in ("all", "gemm"):
+        # calibration only: the library GEMM of the same M x N x K (what an im2col lowering would run, without
+        # the im2col traffic) -- an upper reference for what this GPU sustains on this shape under load
+        a = (torch.rand(B * H * H, 9 * cin, device=dev) * 2 - 1).to(dt)
+        bm = ((torch.rand(9 * cin, cout, device=dev) - 0.5) * 0.1).to(dt)
+        t = timeit(lambda: torch.mm(a, bm))
+        row += f" | lib gemm {t*1e3:7.1f} us {gflop/t:7.0f} TF"
+        tot.setdefault("gemm", [0, 0]); tot["gemm"][0] += gflop; tot["gemm"][1] += t
+        del a, bm
     print(row, flush=True)
 for k, (g, t) in tot.items():
     if t:

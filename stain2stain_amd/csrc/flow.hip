@@ -36,18 +36,32 @@ __global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __re
   if (lane == 0) y[o] = s + (bias ? bias[n] : 0.f);
 }
 
-// dx[b][k] = sum_n dy[b][n] W[n][k]; workgroup = (b, 64 k-columns), 4 waves split n, lanes walk k (coalesced)
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+// dx[b][k] = sum_n dy[b][n] W[n][k]; workgroup = (b, 64 k-columns), 16 waves split n, lanes walk k (coalesced);
+// four independent partial sums per lane keep several loads in flight (the loop is latency-bound otherwise)
+__global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                     float* __restrict__ dx, int B, int K, int N) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y, k = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (k < K)
-    for (int n = wv; n < N; n += 4) s = fmaf(dy[(long)b * N + n], w[(long)n * K + k], s);
-  red[wv][lane] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (k < K) {
+    int n = wv;
+    for (; n + 48 < N; n += 64) {
+      s0 = fmaf(dy[(long)b * N + n], w[(long)n * K + k], s0);
+      s1 = fmaf(dy[(long)b * N + n + 16], w[(long)(n + 16) * K + k], s1);
+      s2 = fmaf(dy[(long)b * N + n + 32], w[(long)(n + 32) * K + k], s2);
+      s3 = fmaf(dy[(long)b * N + n + 48], w[(long)(n + 48) * K + k], s3);
+    }
+    for (; n < N; n += 16) s0 = fmaf(dy[(long)b * N + n], w[(long)n * K + k], s0);
+  }
+  red[wv][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (wv == 0 && k < K) dx[(long)b * K + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (wv == 0 && k < K) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][lane];
+    dx[(long)b * K + k] = s;
+  }
 }
 
 // dW[n][k] (+)= sum_b dy[b][n] x[b][k];  db[n] (+)= sum_b dy[b][n]
@@ -169,7 +183,7 @@ extern "C" int s2s_linear_bwd(const float* dy, const float* x, const float* w, f
   if (!dy || !x || !w || !dw) return S2S_ERR_NULL;
   if (B <= 0 || K <= 0 || N <= 0) return S2S_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(K, 64), B), dim3(256), 0, s, dy, w, dx, B, K, N);
+  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(K, 64), B), dim3(1024), 0, s, dy, w, dx, B, K, N);
   hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(N * (K + 1), 256)), dim3(256), 0, s, dy, x, dw, db, B, K, N,
                      accumulate);
   S2S_LAUNCH_CHECK();

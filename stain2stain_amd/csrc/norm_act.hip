@@ -179,60 +179,82 @@ __global__ void maxpool2_kernel(const T* __restrict__ x, int ldx, T* __restrict_
 //   g = g1 (optional dense / sliced gradient) + max-pool scatter of gp (optional).
 // The pool winner is the FIRST maximum in (0,0),(0,1),(1,0),(1,1) order, as ATen's max_pool2d picks
 // it; ties at 0 are irrelevant because the ReLU mask kills them.
+// The tensors stay in their storage form (16 B per pixel-piece in bf16) until a channel is evaluated, so a thread
+// holds 36 registers of window data instead of 96 fp32 ones; the kernels below then have room for 4+ waves/SIMD.
+typedef __attribute__((ext_vector_type(8))) float f32x8v;
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+template <> struct Vec8<float> { typedef f32x8v type; };
+
+__device__ __forceinline__ bf16x8 vload8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ f32x8v vload8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void vstore8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ void vstore8(float* p, f32x8v v) {
+  *reinterpret_cast<f32x4*>(p) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+  *reinterpret_cast<f32x4*>(p + 4) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+}
+
 template <typename T>
 struct WindowGrad {
-  float dz[4][8];    // g * (y > 0)
-  float xh[4][8];    // normalised conv output
-  bool ok[4];
+  typedef typename Vec8<T>::type V;
+  V x0, x1, x2, x3, g0, g1v, g2, g3, pr;   // conv output / dense gradient at the 4 pixels, pooled gradient
+  int okmask;                               // bit q: pixel q inside the image; bit 4: window has a pool output
   // The ReLU output is not read back: y = relu(x*scale+shift) is recomputed from the saved conv output with the
   // forward's exact fp32 expression (and rounded to the storage type like the forward did), so the mask and the
   // pool winner are bit-identical to the forward's while the backward moves 2 B/element less per pass.
   __device__ __forceinline__ void load(const T* __restrict__ g1, int ldg1, const T* __restrict__ gp, int ldgp,
-                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                       const T* __restrict__ x, int ldx,
-                                       const float* mean, const float* invstd, int n, int wy, int wx, int H,
-                                       int W, int c8) {
+                                       const T* __restrict__ x, int ldx, int n, int wy, int wx, int H, int W,
+                                       int c8) {
     const int Hp = H >> 1, Wp = W >> 1;
-    float yv[4][8];
+    const V zero = {};
+    const int yy = wy * 2, xx = wx * 2;
+    const bool r1 = yy + 1 < H, c1 = xx + 1 < W;
+    okmask = 1 | (c1 ? 2 : 0) | (r1 ? 4 : 0) | ((r1 && c1) ? 8 : 0);
+    const long p00 = ((long)n * H + yy) * W + xx;
+    x0 = vload8(x + p00 * ldx + c8);
+    x1 = c1 ? vload8(x + (p00 + 1) * ldx + c8) : zero;
+    x2 = r1 ? vload8(x + (p00 + W) * ldx + c8) : zero;
+    x3 = (r1 && c1) ? vload8(x + (p00 + W + 1) * ldx + c8) : zero;
+    if (g1) {
+      g0 = vload8(g1 + p00 * ldg1 + c8);
+      g1v = c1 ? vload8(g1 + (p00 + 1) * ldg1 + c8) : zero;
+      g2 = r1 ? vload8(g1 + (p00 + W) * ldg1 + c8) : zero;
+      g3 = (r1 && c1) ? vload8(g1 + (p00 + W + 1) * ldg1 + c8) : zero;
+    } else {
+      g0 = zero; g1v = zero; g2 = zero; g3 = zero;
+    }
+    const bool pooled = gp && wy < Hp && wx < Wp;
+    okmask |= pooled ? 16 : 0;
+    pr = pooled ? vload8(gp + (((long)n * Hp + wy) * Wp + wx) * ldgp + c8) : zero;
+  }
+  __device__ __forceinline__ bool ok(int q) const { return (okmask >> q) & 1; }
+  // channel k of the window: dz[q] = g * (y > 0), xh[q] = normalised conv output
+  __device__ __forceinline__ void eval(int k, float sc, float sh, float mu, float is, float (&dz)[4],
+                                       float (&xh)[4]) const {
+    const float b[4] = {(float)x0[k], (float)x1[k], (float)x2[k], (float)x3[k]};
+    dz[0] = (float)g0[k]; dz[1] = (float)g1v[k]; dz[2] = (float)g2[k]; dz[3] = (float)g3[k];
+    float yv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int yy = wy * 2 + (q >> 1), xx = wx * 2 + (q & 1);
-      ok[q] = yy < H && xx < W;
-      if (ok[q]) {
-        const long pix = ((long)n * H + yy) * W + xx;
-        const f32x8 b = load8(x + pix * ldx + c8);
-        f32x8 g;
-        if (g1) g = load8(g1 + pix * ldg1 + c8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          yv[q][k] = to_f32(from_f32<T>(fmaxf(fmaf(b.v[k], scale[c8 + k], shift[c8 + k]), 0.f)));
-          xh[q][k] = (b.v[k] - mean[c8 + k]) * invstd[c8 + k];
-          dz[q][k] = g1 ? g.v[k] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { yv[q][k] = 0.f; xh[q][k] = 0.f; dz[q][k] = 0.f; }
-      }
+      yv[q] = ok(q) ? to_f32(from_f32<T>(fmaxf(fmaf(b[q], sc, sh), 0.f))) : 0.f;
+      xh[q] = ok(q) ? (b[q] - mu) * is : 0.f;
     }
-    if (gp && wy < Hp && wx < Wp) {
-      const f32x8 p = load8(gp + (((long)n * Hp + wy) * Wp + wx) * ldgp + c8);
+    if (okmask & 16) {
+      int best = 0;
+      float bv = yv[0];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        int best = 0;
-        float bv = yv[0][k];
+      for (int q = 1; q < 4; ++q)
+        if (yv[q] > bv) { bv = yv[q]; best = q; }
+      const float p = (float)pr[k];
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-          if (yv[q][k] > bv) { bv = yv[q][k]; best = q; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q == best) dz[q][k] += p.v[k];
-      }
+      for (int q = 0; q < 4; ++q) dz[q] += (q == best) ? p : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (!(yv[q][k] > 0.f)) dz[q][k] = 0.f;
+      if (!(yv[q] > 0.f)) dz[q] = 0.f;
   }
 };
 
@@ -261,21 +283,33 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
   Acc s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
+  // per-channel constants live in LDS (a thread's 8 channels x 4 arrays would cost 32 VGPRs for the whole loop)
+  __shared__ float kc[4][256];
+  for (int i = threadIdx.x; i < PCB * 8; i += 256) {
+    const int c = blockIdx.x * PCB * 8 + i;
+    const bool in = c < C;
+    kc[0][i] = in ? scale[c] : 0.f; kc[1][i] = in ? shift[c] : 0.f;
+    kc[2][i] = in ? mean[c] : 0.f;  kc[3][i] = in ? invstd[c] : 0.f;
+  }
+  __syncthreads();
   if (c8 < C) {
-    for (long w = (long)blockIdx.y * WL + wl; w < nwin; w += (long)gridDim.y * WL) {
-      long t = w;
-      const int wx = (int)(t % Ww); t /= Ww;
-      const int wy = (int)(t % Hw);
-      const int n = (int)(t / Hw);
+    // 32-bit window index (host checks B*Hw*Ww < 2^31): the 64-bit div/mod sequences cost more than the math
+    for (int w = blockIdx.y * WL + wl; w < (int)nwin; w += gridDim.y * WL) {
+      const int t1 = w / Ww, wx = w - t1 * Ww;
+      const int n = t1 / Hw, wy = t1 - n * Hw;
       WindowGrad<T> wg;
-      wg.load(g1, ldg1, gp, ldgp, scale, shift, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+      wg.load(g1, ldg1, gp, ldgp, x, ldx, n, wy, wx, H, W, c8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
+        float dz[4], xh[4];
+        const int ci = pc * 8 + k;
+        wg.eval(k, kc[0][ci], kc[1][ci], kc[2][ci], kc[3][ci], dz, xh);
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { a += wg.dz[q][k]; b += wg.dz[q][k] * wg.xh[q][k]; }
+        for (int q = 0; q < 4; ++q) { a += dz[q]; b += dz[q] * xh[q]; }
         s1[k] += (Acc)a;
         s2[k] += (Acc)b;
+        __builtin_amdgcn_sched_barrier(0);    // one channel at a time: interleaving all eight costs 60+ VGPRs
       }
     }
   }
@@ -331,29 +365,44 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* g1, int
   float s[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  __shared__ float kc[7][256];
+  for (int i = threadIdx.x; i < PCB * 8; i += 256) {
+    const int c = blockIdx.x * PCB * 8 + i;
+    const bool in = c < C;
+    kc[0][i] = in ? scale[c] : 0.f; kc[1][i] = in ? shift[c] : 0.f;
+    kc[2][i] = in ? mean[c] : 0.f;  kc[3][i] = in ? invstd[c] : 0.f;
+    kc[4][i] = in ? gamma[c] * invstd[c] : 0.f;
+    kc[5][i] = in ? c1[c] : 0.f;    kc[6][i] = in ? c2[c] : 0.f;
+  }
+  __syncthreads();
   if (c8 < C) {
-    float ga[8], k1[8], k2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { ga[k] = gamma[c8 + k] * invstd[c8 + k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k]; }
-    for (long w = (long)blockIdx.y * WL + wl; w < nwin; w += (long)gridDim.y * WL) {
-      long t = w;
-      const int wx = (int)(t % Ww); t /= Ww;
-      const int wy = (int)(t % Hw);
-      const int n = (int)(t / Hw);
+    // 32-bit window index (host checks B*Hw*Ww < 2^31): the 64-bit div/mod sequences cost more than the math
+    for (int w = blockIdx.y * WL + wl; w < (int)nwin; w += gridDim.y * WL) {
+      const int t1 = w / Ww, wx = w - t1 * Ww;
+      const int n = t1 / Hw, wy = t1 - n * Hw;
       WindowGrad<T> wg;
-      wg.load(g1, ldg1, gp, ldgp, scale, shift, x, ldx, mean, invstd, n, wy, wx, H, W, c8);
+      wg.load(g1, ldg1, gp, ldgp, x, ldx, n, wy, wx, H, W, c8);
+      typename Vec8<T>::type o0, o1, o2, o3;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!wg.ok[q]) continue;
-        const long pix = ((long)n * H + wy * 2 + (q >> 1)) * W + wx * 2 + (q & 1);
-        f32x8 o;
+      for (int k = 0; k < 8; ++k) {
+        float dz[4], xh[4];
+        const int ci = pc * 8 + k;
+        wg.eval(k, kc[0][ci], kc[1][ci], kc[2][ci], kc[3][ci], dz, xh);
+        const float gak = kc[4][ci], k1k = kc[5][ci], k2k = kc[6][ci];
+        float v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          o.v[k] = ga[k] * (wg.dz[q][k] - k1[k] - wg.xh[q][k] * k2[k]);
-          s[k] += o.v[k];
+        for (int q = 0; q < 4; ++q) {
+          v[q] = gak * (dz[q] - k1k - xh[q] * k2k);
+          if (wg.ok(q)) s[k] += v[q];
         }
-        store8(dx + pix * lddx + c8, o);
+        o0[k] = from_f32<T>(v[0]); o1[k] = from_f32<T>(v[1]); o2[k] = from_f32<T>(v[2]); o3[k] = from_f32<T>(v[3]);
+        __builtin_amdgcn_sched_barrier(0);    // one channel at a time: interleaving all eight costs 60+ VGPRs
       }
+      T* const d00 = dx + (((long)n * H + wy * 2) * W + wx * 2) * lddx + c8;
+      vstore8(d00, o0);
+      if (wg.ok(1)) vstore8(d00 + lddx, o1);
+      if (wg.ok(2)) vstore8(d00 + (long)W * lddx, o2);
+      if (wg.ok(3)) vstore8(d00 + (long)(W + 1) * lddx, o3);
     }
   }
   if (dxsum_part) {
@@ -578,6 +627,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) ||
       (g1 && (ldg1 % 8)) || (gp && (ldgp % 8)))
     return S2S_ERR_SHAPE;
+  if ((long)B * ((H + 1) / 2) * ((W + 1) / 2) >= (1L << 31) - (1 << 20)) return S2S_ERR_SHAPE;   // 32-bit window index
   const int nb = red_blocks(B, H, W, C);
   float* part = work;                       // [nb][2][C]
   float* part2 = work + (long)nb * 2 * C;   // [nb][C]
