@@ -416,6 +416,120 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const T* __restric
   if (threadIdx.x == 0) lpart[blockIdx.x] = lred[0];
 }
 
+// Lane-per-piece form of the fused head (C = 8*PCB, PCB a power of two <= 64): the PCB lanes of a pixel each
+// own 8 of its channels, so a wave reads and writes whole NHWC pixel rows (the one-thread-per-pixel form above
+// issues 64 different cache lines per load instruction and needs an LDS transpose for dW).  v = W a is finished by
+// a butterfly over the PCB lanes; dW and db accumulate in registers over the workgroup's pixels and are folded
+// once at the end.  Same outputs and workspace as head_loss_fused_kernel.
+template <typename T, int PCB>
+__global__ __launch_bounds__(256) void head_loss_lanes_kernel(const T* __restrict__ x, int ldx,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ u, float* __restrict__ v_out,
+                                                              T* __restrict__ dx, int lddx, float coef,
+                                                              float* __restrict__ part, double* __restrict__ lpart,
+                                                              long npix, int HW, int Cout) {
+  constexpr int C = PCB * 8, PPB = 256 / PCB, MO = HEAD_MAX_COUT;
+  __shared__ float fold[256][MO * 8 + 1];
+  __shared__ float dbf[PPB][MO];
+  __shared__ double lred[256];
+  const int tid = threadIdx.x, pc = tid & (PCB - 1), slot = tid / PCB;
+  const int lane = tid & 63, grp0 = lane & ~(PCB - 1);
+  float wr[MO][8], bo[MO];
+#pragma unroll
+  for (int o = 0; o < MO; ++o) {
+    bo[o] = (o < Cout && bias) ? bias[o] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[o][k] = o < Cout ? w[o * C + pc * 8 + k] : 0.f;
+  }
+  float dwacc[MO][8], dbacc[MO];
+#pragma unroll
+  for (int o = 0; o < MO; ++o) {
+    dbacc[o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dwacc[o][k] = 0.f;
+  }
+  double lsum = 0.0;
+  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+    const long p = p0 + slot;
+    const bool ok = p < npix;
+    f32x8 a;
+    if (ok) a = load8(x + p * ldx + pc * 8);
+    else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
+    }
+    float vv[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t = fmaf(a.v[k], wr[o][k], t);
+#pragma unroll
+      for (int m = 1; m < PCB; m <<= 1) t += __shfl_xor(t, m, 64);
+      vv[o] = t + bo[o];
+    }
+    const long n = p / HW, q = p - n * HW;
+    float gm[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+      gm[o] = 0.f;
+      if (ok && o < Cout && (o & (PCB - 1)) == pc) {        // this lane owns output channel o of the pixel
+        const long idx = (n * Cout + o) * HW + q;
+        if (v_out) v_out[idx] = vv[o];
+        const float d = vv[o] - u[idx];
+        lsum += (double)(d * d);
+        gm[o] = coef * d;
+      }
+    }
+    float g[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) g[o] = __shfl(gm[o], grp0 + (o & (PCB - 1)), 64);
+    if (ok) {
+      f32x8 da;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int o = 0; o < MO; ++o) t = fmaf(g[o], wr[o][k], t);
+        da.v[k] = t;
+      }
+      store8(dx + p * lddx + pc * 8, da);
+    }
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+      if (pc == 0) dbacc[o] += g[o];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dwacc[o][k] = fmaf(g[o], a.v[k], dwacc[o][k]);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < MO; ++o) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fold[tid][o * 8 + k] = dwacc[o][k];
+    if (pc == 0) dbf[slot][o] = dbacc[o];
+  }
+  lred[tid] = lsum;
+  __syncthreads();
+  const int nout = Cout * (C + 1);
+  for (int id = tid; id < nout; id += 256) {
+    const int o = id / (C + 1), c = id - o * (C + 1);
+    float t = 0.f;
+    if (c < C) {
+      const int cp = c >> 3, k = c & 7;
+      for (int sl = 0; sl < PPB; ++sl) t += fold[sl * PCB + cp][o * 8 + k];
+    } else {
+      for (int sl = 0; sl < PPB; ++sl) t += dbf[sl][o];
+    }
+    part[(long)blockIdx.x * nout + id] = t;
+  }
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) lred[tid] += lred[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) lpart[blockIdx.x] = lred[0];
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* part, int n, double inv_count, float* loss) {
   __shared__ double red[256];
   double s = 0.0;
@@ -565,13 +679,33 @@ extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const floa
   if (lds > 60 * 1024) return S2S_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   const float coef = (float)(2.0 * (double)grad_scale / count);
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(head_loss_fused_kernel<bf16_t>, dim3(nb), dim3(256), lds, s, (const bf16_t*)x, ldx, w, bias,
-                       u_nchw, v_nchw, (bf16_t*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
-  else if (dtype == S2S_F32)
-    hipLaunchKernelGGL(head_loss_fused_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)x, ldx, w, bias,
-                       u_nchw, v_nchw, (float*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
-  else return S2S_ERR_DTYPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  static const int lanes_off = [] { const char* e = getenv("S2S_HEAD_LANES"); return e && atoi(e) == 0; }();
+  const int pcb = C / 8;
+  bool done = false;
+#define S2S_HL(TT, PP)                                                                                              \
+  hipLaunchKernelGGL((head_loss_lanes_kernel<TT, PP>), dim3(nb), dim3(256), 0, s, (const TT*)x, ldx, w, bias, u_nchw, \
+                     v_nchw, (TT*)dx, lddx, coef, part, lpart, npix, H * W, Cout);                                 \
+  done = true;
+#define S2S_HL_T(TT)                                                                                    \
+  switch (pcb) {                                                                                        \
+    case 1: { S2S_HL(TT, 1) } break;  case 2: { S2S_HL(TT, 2) } break;  case 4: { S2S_HL(TT, 4) } break;    \
+    case 8: { S2S_HL(TT, 8) } break;  case 16: { S2S_HL(TT, 16) } break; case 32: { S2S_HL(TT, 32) } break;  \
+    case 64: { S2S_HL(TT, 64) } break; default: break;                                                  \
+  }
+  if (!lanes_off) {
+    if (dtype == S2S_BF16) { S2S_HL_T(bf16_t) } else { S2S_HL_T(float) }
+  }
+#undef S2S_HL_T
+#undef S2S_HL
+  if (!done) {
+    if (dtype == S2S_BF16)
+      hipLaunchKernelGGL(head_loss_fused_kernel<bf16_t>, dim3(nb), dim3(256), lds, s, (const bf16_t*)x, ldx, w, bias,
+                         u_nchw, v_nchw, (bf16_t*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
+    else
+      hipLaunchKernelGGL(head_loss_fused_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)x, ldx, w, bias,
+                         u_nchw, v_nchw, (float*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
+  }
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
                      dw, dbias, accumulate);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, lpart, nb, 1.0 / count, loss);

@@ -295,11 +295,13 @@ def test_layout_roundtrip_and_error_status():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_head_loss_fused_matches_separate_ops(dtype):
-    """Fused head conv + MSE + backward (training step) against autograd on the CPU."""
+@pytest.mark.parametrize("C", [8, 16, 64, 24])
+def test_head_loss_fused_matches_separate_ops(dtype, C):
+    """Fused head conv + MSE + backward (training step) against autograd on the CPU.  C = 8, 16, 64 take the
+    lane-per-piece kernel (C/8 a power of two), C = 24 the one-thread-per-pixel form."""
     from stain2stain_amd import ops
     g = torch.Generator().manual_seed(21)
-    B, C, H, W = 2, 16, 19, 23
+    B, H, W = 2, 19, 23
     a = rnd(torch.rand(B, C, H, W, generator=g) * 2 - 1, dtype).requires_grad_(True)
     w = ((torch.rand(3, C, 1, 1, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
     b = (torch.rand(3, generator=g) - 0.5).requires_grad_(True)
@@ -313,5 +315,5 @@ def test_head_loss_fused_matches_separate_ops(dtype):
     assert relerr(v.cpu(), v_ref) < 1e-5
     assert relerr(loss.cpu(), loss_ref) < 1e-5
     assert relerr(nchw(dx), a.grad) < tol_act(dtype)
-    assert relerr(dw.cpu(), w.grad) < (5e-3 if dtype == torch.bfloat16 else 5e-3)   # dW uses a bf16 copy of the activation
+    assert relerr(dw.cpu(), w.grad) < (5e-3 if C == 24 else 1e-4)   # the per-pixel form stages a bf16 copy for dW
     assert relerr(db.cpu(), b.grad) < 1e-4
