@@ -101,7 +101,9 @@ int s2s_bn_bwd_blocks(int B, int H, int W, int C);
 /* g1: gradient wrt the ReLU output (may be NULL if gp given); gp: gradient wrt the pooled output (may be
  * NULL); scale/shift: the forward's folded affine (the ReLU output is recomputed from x, not read);
  * x: saved conv output; work: float[4*blocks*C + 2*C];
- * dbias_conv (optional): gradient of the preceding conv's bias = per-channel sum of dx. */
+ * dbias_conv (optional): gradient of the preceding conv's bias = per-channel sum of dx, which the BatchNorm backward
+ * makes identically zero; written as exact 0 (the reference's autograd sums rounding noise there).  With
+ * S2S_BN_DBIAS_SUM=1 in the environment the sum is formed instead. */
 int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
                     const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                     float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx, float* work, int B, int H,

@@ -566,7 +566,8 @@ extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float*
 extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
   const int nt = B * cdiv(H, 16) * cdiv(W, 16);
-  return nt < 256 ? nt : 256;
+  static const int cap = [] { const char* e = getenv("S2S_STEM_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // 2 per CU: 98 us vs 126 us at 256
+  return nt < cap ? nt : cap;
 }
 
 // part: float[ceil(Cin/3)][2*blocks][Cout][32]

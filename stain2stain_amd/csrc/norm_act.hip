@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
 
 // sums partial[nblk][2][C] -> dgamma, dbeta (accumulate optional) and the two per-channel means
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
-                                       float* dbeta, int accumulate, float* c1, float* c2) {
+                                       float* dbeta, int accumulate, float* c1, float* c2, float* zero_out) {
   __shared__ double s1[32][33], s2[32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
     dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     c1[c] = (float)(a / count);
     c2[c] = (float)(b / count);
+    if (zero_out) zero_out[c] = 0.f;
   }
 }
 
@@ -635,6 +636,14 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   float* c2 = c1 + C;
   const double count = (double)B * H * W;
   hipStream_t s = (hipStream_t)stream;
+  // Gradient of the conv bias that feeds a train-mode BatchNorm: sum over pixels of dx, which the BN backward
+  // formula makes identically zero (sum dz - N c1 - c2 sum xhat, with c1 = sum dz / N and sum xhat = 0).  The
+  // reference's autograd sums it anyway and gets rounding noise of either sign (|.| ~ 1e-9); by default we write the
+  // exact value and skip the partial sums and their two reduction launches per layer.  S2S_BN_DBIAS_SUM=1 restores
+  // the summed form (tests compare the two).
+  static const int dbias_sum = [] { const char* e = getenv("S2S_BN_DBIAS_SUM"); return e ? atoi(e) : 0; }();
+  float* const dbias_zero = (dbias_conv && !dbias_sum && !accumulate) ? dbias_conv : nullptr;
+  if (dbias_conv && !dbias_sum) dbias_conv = nullptr;
   dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
 #define S2S_BN_BWD(TT)                                                                                             \
   if (gp) {                                                                                                        \
@@ -645,7 +654,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
                        scale, shift, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
   }                                                                                                                \
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, prereduce(part, nb, 2 * C, s), \
-                     C, count, dgamma, dbeta, accumulate, c1, c2);                                                                   \
+                     C, count, dgamma, dbeta, accumulate, c1, c2, dbias_zero);                                                       \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
                        ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
