@@ -598,99 +598,117 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
 // ds_read_b128 lane group takes rows {0-3, 12-15} of one piece and rows {4-11} of the next, and this key keeps
 // all sixteen 16-B slots of the bank row distinct (the plain (row >> 2) & 3 key gives a 2-way conflict here).
 // =========================================================================================================
-template <int TH, int TW, int BN, int WM, int WN, int LDS_MAIN>
+// Epilogue of the 16x16x32 kernel.  The main loop issues its MFMAs with the operands swapped (weights as A, pixels
+// as B), so a lane's four accumulator registers are four consecutive output CHANNELS of one pixel: they pack into
+// one 8-byte LDS write of the pixel-major tile (the un-swapped layout needed a lane-pair shuffle and two 4-byte
+// writes per fragment, and that epilogue cost 5.4 us per workgroup -- a third of a 64->64 layer).  The tile is then
+// read back 16 B per thread for coalesced NHWC stores; BatchNorm's partial sums are taken there, from the values as
+// stored (bf16), which is what a BatchNorm behind a bf16 conv normalises.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every global
+// store a wave has issued to be acknowledged (1-2 us in the epilogue, where the stores are fire-and-forget).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int LDS_MAIN, bool AFFINE>
 __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
-                                                char* smem, int img, int y0, int x0p, int n0) {
+                                                const float (&bias)[(BN / WN) / 16][4], char* smem, int img, int y0,
+                                                int x0p, int n0) {
   using T = bf16_t;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   T* __restrict__ yout = static_cast<T*>(a.y);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int cl = lane & 15, q = lane >> 4;
-  constexpr int RS = BN * 2 + 64;
-  constexpr int EP = (BM * RS + WM * 2 * BN * 4 <= LDS_MAIN) ? 1 : ((BM / 2) * RS + WM * 2 * BN * 4 <= LDS_MAIN ? 2 : 4);
+  constexpr int RS = BN * 2 + 16;                          // row stride 4 (mod 64) dwords: 8-byte writes 2-way at worst
+  constexpr int CPR = BN / 8, RG = 256 / CPR;              // 16-byte pieces per pixel row, row groups of the read-back
+  constexpr int RED = RG * 2 * BN * 4;                     // per-row-group partial sums
+  constexpr int EP = (BM * RS + RED <= LDS_MAIN) ? 1 : ((BM / 2) * RS + RED <= LDS_MAIN ? 2 : 4);
   static_assert(WM % EP == 0 || EP == 1, "epilogue passes split the wave rows");
+  static_assert((BM / EP) * RS + RED <= LDS_MAIN, "epilogue staging fits the main-loop LDS");
   constexpr int PM = BM / EP;
   char* const otile = smem;
   float* const red = reinterpret_cast<float*>(smem + PM * RS);
   const bool want_stats = a.stat_part != nullptr;
-  float s1[NI], s2[NI];
+  const bool full = y0 + TH <= a.H && x0p + TW <= a.W && n0 + BN <= a.Cout;
+  // channel constants of this lane: channels wn*WTN + ni*16 + 4q + j (the bias was fetched before the last chunk)
+  float esc[NI][4], esh[NI][4];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * WTN + ni * 16 + 4 * q + j;
+      const bool nok = n < a.Cout;
+      esc[ni][j] = (AFFINE && nok) ? a.ep_scale[n] : 1.f;
+      esh[ni][j] = (AFFINE && nok) ? a.ep_shift[n] : 0.f;
+    }
+  const int c = tid % CPR, rg = tid / CPR;                 // read-back: fixed 8-channel piece, rows rg, rg+RG, ...
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
 #pragma unroll
   for (int ep = 0; ep < EP; ++ep) {
-    if (ep > 0) __syncthreads();
+    if (ep > 0) lds_barrier();
     if (wm / (WM / EP) == ep || EP == 1) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int nl = wn * WTN + ni * 16 + cl;
-        const int n = n0 + nl;
-        const bool nok = n < a.Cout;
-        const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
-        const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
-        const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
-        const bool odd = lane & 1;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int mrow = wm * WTM + mi * 16 + cl - ep * PM;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          float v[4];
+        for (int ni = 0; ni < NI; ++ni) {
+          bf16x4 pk;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int m = wm * WTM + mi * 16 + 4 * q + j;
-            const int py = m / TW, px = m - py * TW;
-            float t = acc[mi][ni][j] + bias;
-            if (a.ep_scale) t = t * esc + esh;
-            if (a.relu) t = fmaxf(t, 0.f);
-            v[j] = t;
-            if (nok && y0 + py < a.H && x0p + px < a.W) { s1[ni] += t; s2[ni] += t * t; }
+            float t = acc[mi][ni][j] + bias[ni][j];
+            if (AFFINE) {
+              t = t * esc[ni][j] + esh[ni][j];
+              if (a.relu) t = fmaxf(t, 0.f);
+            }
+            pk[j] = (bf16_t)t;
           }
-          const int mrow0 = wm * WTM + mi * 16 + 4 * q - ep * PM;
+          *reinterpret_cast<bf16x4*>(otile + mrow * RS + (wn * WTN + ni * 16 + 4 * q) * 2) = pk;
+        }
+      }
+    }
+    lds_barrier();
+    constexpr int O_IT = PM / RG;
+    static_assert(PM % RG == 0, "read-back rows split evenly");
 #pragma unroll
-          for (int j = 0; j < 4; j += 2) {     // lane pair (2k, 2k+1): even lane keeps row j, odd lane row j+1
-            const float got = __shfl_xor(odd ? v[j] : v[j + 1], 1, 64);
-            bf16x2 pk;
-            pk[0] = (bf16_t)(odd ? got : v[j]);
-            pk[1] = (bf16_t)(odd ? v[j + 1] : got);
-            *reinterpret_cast<bf16x2*>(otile + (mrow0 + j + (odd ? 1 : 0)) * RS + (nl & ~1) * 2) = pk;
+    for (int i = 0; i < O_IT; ++i) {
+      const int ml = rg + i * RG;
+      const int m = ml + ep * PM;
+      const int py = m / TW, px = m - py * TW;
+      const int gy = y0 + py, gx = x0p + px, n = n0 + c * 8;
+      if (full || (gy < a.H && gx < a.W && n < a.Cout)) {
+        const bf16x8 val = *reinterpret_cast<const bf16x8*>(otile + ml * RS + c * 16);
+        if (!(a.dbg & 8))
+          *reinterpret_cast<bf16x8*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
+        if (want_stats) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float t = (float)val[k];
+            s1[k] += t;
+            s2[k] = fmaf(t, t, s2[k]);
           }
         }
       }
     }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
-    constexpr int O_IT = (PM * CPR + 255) / 256;
-#pragma unroll
-    for (int i = 0; i < O_IT; ++i) {
-      const int idx = tid + i * 256;
-      const int ml = idx / CPR, c = idx - ml * CPR;
-      const int m = ml + ep * PM;
-      const int py = m / TW, px = m - py * TW;
-      const int gy = y0 + py, gx = x0p + px, n = n0 + c * 8;
-      if (idx < PM * CPR && gy < a.H && gx < a.W && n < a.Cout) {
-        const f32x4 val = *reinterpret_cast<const f32x4*>(otile + ml * RS + c * 16);
-        *reinterpret_cast<f32x4*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
-      }
-    }
   }
   if (want_stats) {
+    // red[rg][which][BN]; channels past Cout hold zeros (their rows were skipped above) and are not written out
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int nl = wn * WTN + ni * 16 + cl;
-      float t1 = s1[ni], t2 = s2[ni];
-      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (q == 0) {
-        red[(wm * 2 + 0) * BN + nl] = t1;
-        red[(wm * 2 + 1) * BN + nl] = t2;
-      }
+    for (int k = 0; k < 8; ++k) {
+      red[(rg * 2 + 0) * BN + c * 8 + k] = s1[k];
+      red[(rg * 2 + 1) * BN + c * 8 + k] = s2[k];
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, nl = i - which * BN;
       if (n0 + nl < a.Cout) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < WM; ++k) s += red[(k * 2 + which) * BN + nl];
-        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = s;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < RG; ++k) sum += red[(k * 2 + which) * BN + nl];
+        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = sum;
       }
     }
   }
@@ -706,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   constexpr int B_BYTES = BN * 64;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int RB = TW / 16;                        // 16-pixel blocks per tile row
-  static_assert(WM * WN == 4 && BN % 64 == 0 && (NS == 3 || NS == 4) && TW % 16 == 0 && WTM % TW == 0, "configuration");
+  static_assert(WM * WN == 4 && BN % 64 == 0 && NS >= 3 && NS <= 8 && TW % 16 == 0 && WTM % TW == 0, "configuration");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsA = smem;
@@ -803,16 +821,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)   // weights as A, pixels as B: the result tile is [channel][pixel] (see the epilogue)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   };
-
   dma_halo(0);
   static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
   int c = 0;
+  if (a.dbg & 32) c = a.nchunk - 1;
   for (; c + 1 < a.nchunk; ++c) {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
     const int it0 = c * 9;
@@ -826,6 +844,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_s_barrier();
     });
   }
+  // the epilogue's per-channel bias: fetched here so that the load latency hides behind the last nine taps
+  float biasr[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * WTN + ni * 16 + 4 * kp + j;
+      biasr[ni][j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+    }
   {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
     const int it0 = c * 9;
@@ -838,19 +865,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_s_barrier();
     });
   }
-  conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES>(a, acc, smem, img, y0, x0p, n0);
+  if (a.dbg & 16) return;
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0);
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   constexpr int ROWS = (TH + 2) * (TW + 4);
   constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
-  constexpr int lds_main = 2 * HG * 4 * 1024 + NS * BN * 64;
-  constexpr int RS_ = BN * 2 + 64;
-  constexpr int red_ = WM * 2 * BN * 4;
-  constexpr int EP_ = (TH * TW * RS_ + red_ <= lds_main) ? 1 : ((TH * TW / 2) * RS_ + red_ <= lds_main ? 2 : 4);
-  constexpr int lds_epi = (TH * TW / EP_) * RS_ + red_;
-  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr int lds = 2 * HG * 4 * 1024 + NS * BN * 64;      // the epilogue stages inside this (static_assert there)
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
@@ -1102,7 +1126,12 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
   if (use_dma == 16) {
     switch (id) {
       case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
-      case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
+      case 1: {
+        static const int ns = [] { const char* e = getenv("S2S_CONV_NS64"); return e ? atoi(e) : 4; }();
+        if (ns == 8) return launch_dma16<8, 32, 64, 4, 1, 8>(a, s);
+        if (ns == 6) return launch_dma16<8, 32, 64, 4, 1, 6>(a, s);
+        return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
+      }
       case 2: return launch_dma16<4, 32, 128, 2, 2, 4>(a, s);
       case 3: return launch_dma16<4, 32, 64, 2, 2, 4>(a, s);
       case 4: return launch_dma16<16, 16, 128, 2, 2, 4>(a, s);
