@@ -1,0 +1,46 @@
+"""Turn gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into the summaries committed under profiles/:
+<tag>_bench.json, <tag>_bench_under_rocprof.json, <tag>_kernel_stats.csv, <tag>_hbm_traffic.json (+ the copy
+bench.py reads, hbm_traffic_current.json).  HBM bytes per launch follow MI355X_MICROARCH.md's HBM section:
+separate --pmc passes for FETCH_SIZE and WRITE_SIZE (KB units), FETCH_SIZE doubled for gfx950's wide reads."""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
+shutil.copy(f"{src}/stats/k_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+fetch = per_kernel(f"{src}/pmc_fetch/f_counter_collection.csv", "FETCH_SIZE")
+write = per_kernel(f"{src}/pmc_write/w_counter_collection.csv", "WRITE_SIZE")
+groups = {"conv3x3_mfma (fwd+dgrad, conv3x3_dma16_kernel)": "conv3x3_dma16_kernel",
+          "conv3x3_wgrad (conv3x3_wgrad_dma_kernel)": "conv3x3_wgrad_dma_kernel",
+          "bn_relu_apply": "bn_relu_apply_kernel", "bn_relu_bwd_reduce_flat": "bn_relu_bwd_reduce_flat_kernel",
+          "bn_relu_bwd_apply_flat": "bn_relu_bwd_apply_flat_kernel", "upsample2x_fwd": "upsample2x_fwd_kernel",
+          "upsample2x_bwd": "upsample2x_bwd_kernel", "adam": "adam_kernel", "head_loss": "head_loss_lanes_kernel"}
+out = {}
+for label, needle in groups.items():
+    f = [v for k, vs in fetch.items() if needle in k for v in vs]
+    w = [v for k, vs in write.items() if needle in k for v in vs]
+    if not f or not w:
+        continue
+    fk, wk = sum(f) / len(f), sum(w) / len(w)
+    out[label] = {"launches_sampled": len(f), "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
+                  "hbm_bytes_per_launch_raw": int((fk + wk) * 1024),
+                  "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024),
+                  "note": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); "
+                          "corrected = 2*FETCH + WRITE"}
+json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/hbm_traffic_current.json", "w"), indent=1)
+for k, v in out.items():
+    print(f"{k:55s} {v['hbm_bytes_per_launch_corrected']/1e6:9.1f} MB/launch over {v['launches_sampled']} launches")

@@ -155,20 +155,26 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ d
   }
 }
 
-// one workgroup per (output channel, channel group): 32 k-columns x 8 slab groups
-__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
+// one workgroup per (output channel, channel group): 32 k-columns x 32 slab groups (1024 slabs: 32 loads a thread)
+__global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* part, int nslab, int Cout, int Cin, float* dw, float* db,
                                          int accumulate) {
-  __shared__ double red[8][33];
+  __shared__ double red[32][33];
   const int c0 = blockIdx.y * 3;
   const int K = ((Cin - c0) < 3 ? (Cin - c0) : 3) * 9;
   const int co = blockIdx.x, k = threadIdx.x & 31, sg = threadIdx.x >> 5;
   part += (long)blockIdx.y * nslab * Cout * 32;
-  double s = 0.0;
-  for (int b = sg; b < nslab; b += 8) s += (double)part[((long)b * Cout + co) * 32 + k];
+  double s = 0.0, s1 = 0.0;
+  int b = sg;
+  for (; b + 32 < nslab; b += 64) {
+    s += (double)part[((long)b * Cout + co) * 32 + k];
+    s1 += (double)part[((long)(b + 32) * Cout + co) * 32 + k];
+  }
+  for (; b < nslab; b += 32) s += (double)part[((long)b * Cout + co) * 32 + k];
+  s += s1;
   red[sg][k] = s;
   __syncthreads();
   if (sg == 0) {
-    for (int j = 1; j < 8; ++j) s += red[j][k];
+    for (int j = 1; j < 32; ++j) s += red[j][k];
     if (k < K) {
       float* dst = dw + co * Cin * 9 + c0 * 9 + k;
       *dst = accumulate ? *dst + (float)s : (float)s;
@@ -286,19 +292,26 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
-// part[nblk][nout] -> dw/db; 32 outputs x 8 block groups per workgroup
+// part[nblk][nout] -> dw/db; 8 outputs x 32 block groups per workgroup (the 195 outputs of the 64 -> 3 head give
+// 25 workgroups; with 32 outputs each there were 7 and the 1024-row sum took 34 us)
 __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* part, int nblk, int Cout, int C, float* dw, float* db,
                                          int accumulate) {
-  __shared__ double red[8][33];
+  __shared__ double red[32][9];
   const int nout = Cout * (C + 1);
-  const int i = blockIdx.x * 32 + (threadIdx.x & 31), sg = threadIdx.x >> 5;
+  const int ol = threadIdx.x & 7, sg = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + ol;
   double s = 0.0;
-  if (i < nout)
-    for (int b = sg; b < nblk; b += 8) s += (double)part[(long)b * nout + i];
-  red[sg][threadIdx.x & 31] = s;
+  if (i < nout) {
+    double s1 = 0.0;
+    int b = sg;
+    for (; b + 32 < nblk; b += 64) { s += (double)part[(long)b * nout + i]; s1 += (double)part[(long)(b + 32) * nout + i]; }
+    for (; b < nblk; b += 32) s += (double)part[(long)b * nout + i];
+    s += s1;
+  }
+  red[sg][ol] = s;
   __syncthreads();
   if (sg == 0 && i < nout) {
-    for (int j = 1; j < 8; ++j) s += red[j][threadIdx.x & 31];
+    for (int j = 1; j < 32; ++j) s += red[j][ol];
     const int o = i / (C + 1), c = i - o * (C + 1);
     if (c == C && !db) return;
     float* dst = (c < C) ? dw + o * C + c : db + o;
@@ -596,7 +609,7 @@ extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, lddy, x_nchw, part, B, H,
                        W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else return S2S_ERR_DTYPE;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout, cdiv(Cin, 3)), dim3(256), 0, s, part, 2 * nb, Cout, Cin, dw_oihw, dbias,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout, cdiv(Cin, 3)), dim3(1024), 0, s, part, 2 * nb, Cout, Cin, dw_oihw, dbias,
                      accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -652,7 +665,7 @@ extern "C" int s2s_head_conv1x1_bwd(int dtype, const float* dy_nchw, const void*
   else if (dtype == S2S_F32) { if (mo == 4) { S2S_HEAD_BWD(float, 4) } else { S2S_HEAD_BWD(float, 8) } }
   else return S2S_ERR_DTYPE;
 #undef S2S_HEAD_BWD
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 8)), dim3(256), 0, s, part, nb, Cout, C,
                      dw, dbias, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -707,7 +720,7 @@ extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const floa
       hipLaunchKernelGGL(head_loss_fused_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)x, ldx, w, bias,
                          u_nchw, v_nchw, (float*)dx, lddx, coef, part, lpart, npix, H * W, C, Cout);
   }
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 32)), dim3(256), 0, s, part, nb, Cout, C,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(cdiv(Cout * (C + 1), 8)), dim3(256), 0, s, part, nb, Cout, C,
                      dw, dbias, accumulate);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, lpart, nb, 1.0 / count, loss);
   S2S_LAUNCH_CHECK();
