@@ -69,6 +69,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true",
                     help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
+    ap.add_argument("--mode", default="train", choices=["train", "sample"],
+                    help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
+                         "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
+    ap.add_argument("--euler-steps", type=int, default=50)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,10 +88,58 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from stain2stain_amd import CFMTrainer, FlowUNet, ops
+    from stain2stain_amd import CFMTrainer, FlowUNet, euler_generate, ops
 
     torch.manual_seed(1984)
     net = FlowUNet(3, FEATURES, 3, 256, precision=args.precision).to(dev).train()
+    if args.mode == "sample":
+        # replicas only: every rank integrates its own batch, no collective on the data path
+        B = 32 if args.batch == BATCH_PER_GPU else args.batch
+        g = torch.Generator().manual_seed(1984 + rank)
+        src = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
+        net.eval()
+        for _ in range(max(1, args.warmup // 3)):
+            euler_generate(net, src, args.euler_steps)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ops.profile_start(("conv3x3_mfma",))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = euler_generate(net, src, args.euler_steps)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = ops.profile_stop()
+        if use_dist:
+            el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el)
+        if rank == 0:
+            n_l = len(prof)
+            t_l = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
+            f_l = sum(w for _, w, _, _ in prof)
+            print(json.dumps({
+                "metric": f"256x256 tiles/sec sampled ({args.euler_steps} Euler steps, eval-mode network)",
+                "value": round(B * world * args.steps / elapsed, 3), "unit": "tiles/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                "data": "synthetic",
+                "config": {"workload": f"CFM U-Net {FEATURES} 3x256x256, batch {B}/GPU, {args.euler_steps} Euler "
+                                       "steps (BatchNorm folded into the conv epilogue)",
+                           "global_batch": B * world, "parallelism": f"replicas x{world}",
+                           "finite": bool(torch.isfinite(out).all())},
+                "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (forward launches)",
+                             "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             "traffic": None, "launches_per_step": n_l // args.steps,
+                             "avg_launch_ms": round(t_l * 1e3 / n_l, 4)}}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
     g = torch.Generator().manual_seed(1984 + rank)
     B = args.batch

@@ -31,6 +31,9 @@ BN_MOMENTUM = 0.1
 # ------------------------------------------------------------------------------------------------
 # parameter bundles
 # ------------------------------------------------------------------------------------------------
+mutation_epoch = [0]     # see ConvBN.eval_affine
+
+
 class ConvBN:
     """One Conv3x3 + BatchNorm2d pair of a DoubleConv, with its packed MFMA weight cache."""
 
@@ -40,6 +43,7 @@ class ConvBN:
         self.conv, self.bn = conv, bn
         self._pack: Dict[torch.dtype, Tuple] = {}
         self._pack_key: Dict[torch.dtype, Tuple] = {}
+        self._eval_key, self._eval_ss = None, None
 
     @property
     def cout(self) -> int:
@@ -62,6 +66,19 @@ class ConvBN:
 
     def invalidate(self) -> None:
         self._pack_key.clear()
+
+    def eval_affine(self):
+        """Folded eval-mode BatchNorm (scale, shift), cached until a parameter / running statistic changes.
+        Kernels that write those tensors through raw pointers (train-mode finalize, the fused Adam) do not bump
+        torch's version counters, so they bump ``mutation_epoch`` instead."""
+        bn = self.bn
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = (mutation_epoch[0],) + tuple((t.data_ptr(), t._version) for t in ts)
+        if self._eval_key != key:
+            self._eval_ss = ops.bn_eval_prepare(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                bn.running_var, bn.eps)
+            self._eval_key = key
+        return self._eval_ss
 
     def ensure_buffers(self, dtype: torch.dtype):
         """Allocate (once) the packed buffers without filling them; returns (wf, wd)."""
@@ -124,13 +141,14 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
         count = raw.shape[0] * raw.shape[1] * raw.shape[2]
         track = bn.track_running_stats and bn.running_mean is not None
+        mutation_epoch[0] += 1
         st = ops.bn_finalize(stat, count, bn.weight.detach(), bn.bias.detach(),
                              bn.running_mean if track else None, bn.running_var if track else None,
                              bn.num_batches_tracked if track else None,
                              BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps)
         act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
         return LayerCtx(x0, x1, raw, act, st), act, pooled
-    ss = ops.bn_eval_prepare(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+    ss = cb.eval_affine()
     if stem:
         raw, _ = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=False)
         act, pooled = ops.bn_relu_apply(raw, ss[0], ss[1], want_pool=want_pool)

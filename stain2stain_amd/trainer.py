@@ -138,6 +138,7 @@ class CFMTrainer:
         self.step_count += 1
         ops.adam_step_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas[0],
                        self.betas[1], self.eps, self.wd, self.bucketer.grad_scale)
+        engine.mutation_epoch[0] += 1
         self._repack()              # master weights changed behind torch's version counter
 
     # ------------------------------------------------------------------------------------------
