@@ -49,7 +49,7 @@ def _param_groups(net: FlowUNet) -> List[List[Tuple[str, str, torch.nn.Parameter
 class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
-                 bucket_mb: float = 32.0, process_group=None, sync_loss: bool = True):
+                 bucket_mb: float = 4.0, process_group=None, sync_loss: bool = True):
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: CFMTrainer needs the network on a GPU (HIP-only implementation)")
