@@ -140,6 +140,9 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         else:
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
         count = raw.shape[0] * raw.shape[1] * raw.shape[2]
+        if count <= 1:      # torch.nn.functional.batch_norm raises the same way in training mode
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                             f"{[raw.shape[0], raw.shape[3], raw.shape[1], raw.shape[2]]}")
         track = bn.track_running_stats and bn.running_mean is not None
         mutation_epoch[0] += 1
         st = ops.bn_finalize(stat, count, bn.weight.detach(), bn.bias.detach(),

@@ -171,3 +171,45 @@ def test_production_shape_layer_statistics_bf16():
     losses = [float(tr.step(x0, x1, t)) for _ in range(4)]
     assert all(l == l and l < 10 for l in losses)
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 16, 48), (3, 40, 24)])
+def test_five_level_net_on_tiny_maps_matches_oracle(shape):
+    """Edge sizes: the production depth (5 levels) on maps that shrink to 2x2 / 1x3 at the bottleneck, batch 1-3
+    (every conv tile is mostly padding, BatchNorm over a handful of pixels).  Forward and loss at 1e-3; gradients by
+    their overall L2 error (a max-norm bound would need a screened draw)."""
+    from oracle import unet_oracle as O
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    B, H, W = shape
+    torch.manual_seed(100 + H)
+    net = FlowUNet(3, [8, 16, 16, 32, 32], 3, 16, precision="fp32")
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV).train()
+    g = torch.Generator().manual_seed(H * W)
+    x0 = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    x1 = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    t = torch.rand(B, generator=g)
+    tr = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    loss, v = tr.forward_backward(x0.to(DEV), x1.to(DEV), t.to(DEV))
+    rl, rv, rg, _ = O.loss_and_grads(P, x0, x1, t)
+    assert relerr(v, rv) < TOL and relerr(loss, rl) < TOL
+    num = den = 0.0
+    for k, p in list(net.encoder.named_parameters()) + list(net.flow_decoder.named_parameters()):
+        pre = "encoder." if any(p is q for q in net.encoder.parameters()) else "flow_decoder."
+        r = rg[pre + k]
+        num += float(((p.grad.cpu() - r) ** 2).sum())
+        den += float((r ** 2).sum())
+    assert (num / den) ** 0.5 < 1e-2
+
+
+def test_single_value_batchnorm_raises_like_torch():
+    """A 1x1 map at batch 1 in training mode: torch's batch_norm refuses it, so do we (and eval mode runs)."""
+    from stain2stain_amd import FlowUNet
+    net = FlowUNet(3, [8, 16], 3, 16, precision="fp32").to(DEV).train()
+    x = torch.rand(1, 3, 2, 2, device=DEV)
+    t = torch.rand(1, device=DEV)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        net(t, x)
+    net.eval()
+    with torch.no_grad():
+        assert net(t, x).shape == (1, 3, 2, 2)
