@@ -281,36 +281,72 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
+  // Per-lane, tile-invariant parts of the DMA source addresses (which pixel of the tile / halo, which tensor and
+  // channel); per tile only a wave-uniform pixel base changes.  Interior tiles (the whole halo inside the image)
+  // take a path with no per-lane bounds tests: the address arithmetic otherwise costs a third of the loop's issue
+  // slots (measured: 3.3 us per 128-pixel tile against 2.2 us of MFMA for the two waves of a SIMD).
+  int dy_off[DYG], dy_py[DYG], dy_px[DYG];
+  bool dy_ok[DYG];
+#pragma unroll
+  for (int j = 0; j < DYG; ++j) {
+    const int grp = wave + 4 * j;                  // half = grp / 8, rows (grp % 8) * 16 ..
+    const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
+    const int co = co0 + half * 32 + dslot * 8;
+    dy_py[j] = px / TW; dy_px[j] = px - dy_py[j] * TW;
+    dy_ok[j] = co < a.Cout;
+    dy_off[j] = (dy_py[j] * a.W + dy_px[j]) * a.lddy + co;
+  }
+  const T* x_ptr[XG];
+  int x_off[XG], x_ld[XG], x_hy[XG], x_hx[XG];
+#pragma unroll
+  for (int j = 0; j < XG; ++j) {
+    const int grp = wave + 4 * j;
+    const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
+    const int ci = ci0 + half * 32 + dslot * 8;
+    x_hy[j] = px / HW_; x_hx[j] = px - x_hy[j] * HW_;
+    x_ptr[j] = nullptr; x_ld[j] = 0;
+    if (px < HALO) {
+      if (ci < a.c0) { x_ptr[j] = x0 + ci; x_ld[j] = a.ld0; }
+      else if (ci < cin) { x_ptr[j] = x1 + (ci - a.c0); x_ld[j] = a.ld1; }
+    }
+    x_off[j] = ((x_hy[j] - 1 + kh0) * a.W + (x_hx[j] - 1)) * x_ld[j];
+  }
+
   auto dma_tile = [&](int tile, int buf) {
     int bt = tile;
     const int tx = bt % a.tilesX; bt /= a.tilesX;
     const int ty = bt % a.tilesY;
     const int img = bt / a.tilesY;
     const int y0 = ty * TH, xs = tx * TW;
+    const long pixbase = (long)(img * a.H + y0) * a.W + xs;           // wave-uniform
+    const bool interior = y0 >= 1 && y0 + TH + 1 <= a.H && xs >= 1 && xs + TW + 1 <= a.W;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
+    if (interior) {
 #pragma unroll
-    for (int j = 0; j < DYG; ++j) {
-      const int grp = wave + 4 * j;                  // 0..15: half = grp / 8, rows (grp % 8) * 16 ..
-      const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
-      const int py = px / TW, pxx = px - py * TW;
-      const int gy = y0 + py, gx = xs + pxx, co = co0 + half * 32 + dslot * 8;
-      const void* src = g_wgrad_zero_page;
-      if (gy < a.H && gx < a.W && co < a.Cout) src = dy + ((long)(img * a.H + gy) * a.W + gx) * a.lddy + co;
-      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + grp * 1024));
-    }
-#pragma unroll
-    for (int j = 0; j < XG; ++j) {
-      const int grp = wave + 4 * j;
-      const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
-      const int hy = px / HW_, hx = px - hy * HW_;
-      const int gy = y0 - 1 + kh0 + hy, gx = xs - 1 + hx, ci = ci0 + half * 32 + dslot * 8;
-      const void* src = g_wgrad_zero_page;
-      if (px < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const long pix = (long)(img * a.H + gy) * a.W + gx;
-        if (ci < a.c0) src = x0 + pix * a.ld0 + ci;
-        else if (ci < cin) src = x1 + pix * a.ld1 + (ci - a.c0);
+      for (int j = 0; j < DYG; ++j) {
+        const void* src = dy_ok[j] ? (const void*)(dy + pixbase * a.lddy + dy_off[j]) : (const void*)g_wgrad_zero_page;
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
       }
-      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + grp * 1024));
+#pragma unroll
+      for (int j = 0; j < XG; ++j) {
+        const void* src = x_ptr[j] ? (const void*)(x_ptr[j] + pixbase * x_ld[j] + x_off[j]) : (const void*)g_wgrad_zero_page;
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DYG; ++j) {
+        const int gy = y0 + dy_py[j], gx = xs + dy_px[j];
+        const void* src = g_wgrad_zero_page;
+        if (gy < a.H && gx < a.W && dy_ok[j]) src = dy + pixbase * a.lddy + dy_off[j];
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+      }
+#pragma unroll
+      for (int j = 0; j < XG; ++j) {
+        const int gy = y0 - 1 + kh0 + x_hy[j], gx = xs - 1 + x_hx[j];
+        const void* src = g_wgrad_zero_page;
+        if (x_ptr[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = x_ptr[j] + pixbase * x_ld[j] + x_off[j];
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+      }
     }
   };
 
