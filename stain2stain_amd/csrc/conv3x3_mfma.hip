@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   constexpr int B_BYTES = BN * 64;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int RB = TW / 16;                        // 16-pixel blocks per tile row
-  static_assert(WM * WN == 4 && BN % 64 == 0 && NS >= 3 && NS <= 8 && TW % 16 == 0 && WTM % TW == 0, "configuration");
+  static_assert(WM * WN == 4 && BN % 64 == 0 && (NS == 3 || NS == 4) && TW % 16 == 0 && WTM % TW == 0, "configuration");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsA = smem;
@@ -1126,12 +1126,7 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
   if (use_dma == 16) {
     switch (id) {
       case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
-      case 1: {
-        static const int ns = [] { const char* e = getenv("S2S_CONV_NS64"); return e ? atoi(e) : 4; }();
-        if (ns == 8) return launch_dma16<8, 32, 64, 4, 1, 8>(a, s);
-        if (ns == 6) return launch_dma16<8, 32, 64, 4, 1, 6>(a, s);
-        return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
-      }
+      case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
       case 2: return launch_dma16<4, 32, 128, 2, 2, 4>(a, s);
       case 3: return launch_dma16<4, 32, 64, 2, 2, 4>(a, s);
       case 4: return launch_dma16<16, 16, 128, 2, 2, 4>(a, s);
