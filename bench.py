@@ -73,6 +73,9 @@ def main() -> None:
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
     ap.add_argument("--euler-steps", type=int, default=50)
+    ap.add_argument("--h2d", action="store_true",
+                    help="PCIe-inclusive variant for DESIGN.md: every step copies a fresh uint8 batch from pinned host "
+                         "memory and runs the GPU crop/flip/normalise kernel before the optimisation step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +150,39 @@ def main() -> None:
     x1 = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
     ts = [torch.rand(B, generator=g).to(dev) for _ in range(args.warmup + args.steps)]
 
+    feed = None
+    if args.h2d:
+        from stain2stain_amd import data as s2s_data
+        import random
+        SRC = TILE + 32                                    # decoded images a little larger than the crop
+        host = [torch.randint(0, 256, (B, SRC, SRC, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
+        rng = random.Random(1984 + rank)
+
+        side = torch.cuda.Stream(device=dev)              # copies + preparation of batch i+1 overlap step i
+        pending = {}
+
+        def stage(i):
+            with torch.cuda.stream(side):
+                hs, ht = host[(2 * i) % 4], host[(2 * i + 1) % 4]
+                ds, dtg = hs.to(dev, non_blocking=True), ht.to(dev, non_blocking=True)
+                prm = s2s_data.sample_crop_flip_params(B, (SRC, SRC), TILE, rng)
+                a, b = s2s_data.paired_crop_flip_normalize(ds, dtg, prm, TILE)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            pending[i] = (a, b, ev)
+
+        def feed(i):
+            if i not in pending:
+                stage(i)
+            a, b, ev = pending.pop(i)
+            torch.cuda.current_stream().wait_event(ev)
+            a.record_stream(torch.cuda.current_stream()); b.record_stream(torch.cuda.current_stream())
+            stage(i + 1)
+            return a, b
+
     for i in range(args.warmup):
+        if feed:
+            x0, x1 = feed(i)
         trainer.step(x0, x1, ts[i])
     torch.cuda.synchronize()
     if use_dist:
@@ -158,6 +193,8 @@ def main() -> None:
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
+        if feed:
+            x0, x1 = feed(args.warmup + i)
         loss = trainer.step(x0, x1, ts[args.warmup + i])
     torch.cuda.synchronize()
     if use_dist:
@@ -199,7 +236,8 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic" + (" (uint8 tiles copied from pinned host memory every step)"
+                                                           if args.h2d else ""),
             "config": {"workload": "CFM U-Net [64,128,256,512,1024] 3x256x256 H&E->IHC tiles, "
                                    f"batch {B}/GPU, sample+fwd+loss+bwd+allreduce+Adam",
                        "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
