@@ -1,3 +1,5 @@
+"""Host-side cost of one training step (Python + ctypes launches) with the GPU work stubbed out by timing only the
+enqueue: tells whether the step is launch-bound (it is not: the GPU time per step exceeds the enqueue time)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

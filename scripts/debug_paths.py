@@ -1,3 +1,5 @@
+"""Compares the autograd-module path and the fused-trainer path tensor by tensor on the golden tiny step and counts
+ReLU decisions within fp32 rounding of zero (the knife-edge analysis quoted in tests/test_e2e_gpu.py)."""
 import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import torch
 from conftest import load_golden, sub

@@ -1,3 +1,5 @@
+"""Per-parameter gradient error of the HIP path against the golden tiny step (fp32 mode): the table behind the
+6.8e-6 figure in DESIGN.md section 3.3."""
 import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import torch
 from conftest import load_golden, sub
