@@ -1,5 +1,5 @@
-"""Host-side cost of one training step (Python + ctypes launches) with the GPU work stubbed out by timing only the
-enqueue: tells whether the step is launch-bound (it is not: the GPU time per step exceeds the enqueue time)."""
+"""Host enqueue time of one training step (Python + ctypes launches) against its total time, at batch 16 and in the
+launch-bound regime of batch 2: the headline step is GPU-bound (enqueue time < GPU time)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

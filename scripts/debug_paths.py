@@ -1,5 +1,6 @@
-"""Compares the autograd-module path and the fused-trainer path tensor by tensor on the golden tiny step and counts
-ReLU decisions within fp32 rounding of zero (the knife-edge analysis quoted in tests/test_e2e_gpu.py)."""
+"""Walks the golden tiny step (post-step-0 parameters) layer by layer through the CPU oracle and the HIP engine and
+prints, per activation, the relative error and the number of ReLU decisions that differ (the knife-edge analysis
+quoted in tests/test_e2e_gpu.py)."""
 import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import torch
 from conftest import load_golden, sub
