@@ -46,6 +46,27 @@ def _param_groups(net: FlowUNet) -> List[List[Tuple[str, str, torch.nn.Parameter
     return groups
 
 
+class FusedAdamHandle(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` face for the trainer's fused Adam, so that the reference's schedulers
+    (``ReduceLROnPlateau`` in configs/model/*.yaml:12-16, driven by Lightning on ``val/loss``) and anything else that
+    edits ``optimizer.param_groups[0]["lr"]`` work unchanged: the trainer reads its hyper-parameters from this
+    param group at every step.  ``step()`` runs the trainer's optimiser step (join the all-reduce, fused Adam,
+    repack)."""
+
+    def __init__(self, trainer: "CFMTrainer", lr, betas, eps, weight_decay):
+        self._trainer = trainer
+        super().__init__([trainer.flat_p], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._trainer.optimizer_step()
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False) -> None:      # every backward overwrites the flat gradient buffer
+        pass
+
+
 class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
@@ -54,7 +75,7 @@ class CFMTrainer:
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: CFMTrainer needs the network on a GPU (HIP-only implementation)")
         self.net = net
-        self.lr, self.wd, self.betas, self.eps, self.sigma = lr, weight_decay, betas, eps, sigma
+        self.sigma = sigma
         self.pg = process_group
         self.sync_loss = sync_loss
         self.step_count = 0
@@ -83,6 +104,7 @@ class CFMTrainer:
                     p.grad = gv
                     (self.grads_dec if owner == "dec" else self.grads_enc)[name] = gv
         self._slot = {id(p): (offs[(owner, name)], p.numel()) for g in groups for owner, name, p in g}
+        self.optimizer = FusedAdamHandle(self, lr, betas, eps, weight_decay)
         self.n_params = sum(p.numel() for g in groups for _, _, p in g)
         self.n_dec_groups = 2 + len(net.flow_decoder.ups)
         self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group)
@@ -99,6 +121,16 @@ class CFMTrainer:
         self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._pack_total = start
         self._repack()
+
+    # hyper-parameters live in the optimiser handle's param group (schedulers edit them there)
+    @property
+    def _hp(self):
+        return self.optimizer.param_groups[0]
+
+    lr = property(lambda self: self._hp["lr"], lambda self, v: self._hp.__setitem__("lr", v))
+    wd = property(lambda self: self._hp["weight_decay"], lambda self, v: self._hp.__setitem__("weight_decay", v))
+    betas = property(lambda self: self._hp["betas"], lambda self, v: self._hp.__setitem__("betas", tuple(v)))
+    eps = property(lambda self: self._hp["eps"], lambda self, v: self._hp.__setitem__("eps", v))
 
     # ------------------------------------------------------------------------------------------
     def forward_backward(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None,

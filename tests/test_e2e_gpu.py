@@ -240,3 +240,29 @@ def test_forty_training_steps_track_the_oracle():
     got = euler_generate(net, src.to(DEV), 5).cpu()
     want = O.euler_sample(Pf, src, 5)
     assert relerr(got, want) < 5e-2
+
+
+def test_reference_scheduler_drives_the_fused_trainer():
+    """configs/model/*.yaml pair Adam with ReduceLROnPlateau(mode=min, factor=0.1, patience=10): the scheduler edits
+    optimizer.param_groups[0]['lr'], and the fused Adam must follow.  First Adam steps move every weight by ~lr."""
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    torch.manual_seed(3)
+    net = FlowUNet(3, [16, 32], 3, 32, precision="fp32").to(DEV).train()
+    tr = CFMTrainer(net, lr=1e-3, weight_decay=0.0)
+    assert isinstance(tr.optimizer, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(tr.optimizer, mode="min", factor=0.1, patience=0)
+    g = torch.Generator().manual_seed(4)
+    x0 = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    x1 = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    w = net.encoder.inc.double_conv[3].weight
+    before = w.detach().clone()
+    tr.step(x0, x1)
+    step1 = float((w.detach() - before).abs().max())
+    assert 0.5e-3 < step1 < 1.5e-3
+    sched.step(1.0); sched.step(2.0)                       # a worse metric with patience 0: lr -> 1e-4
+    assert abs(tr.lr - 1e-4) < 1e-12
+    before = w.detach().clone()
+    tr.forward_backward(x0, x1)
+    tr.optimizer.step()                                     # the handle's step() is the trainer's optimiser step
+    step2 = float((w.detach() - before).abs().max())
+    assert step2 < 0.3 * step1
