@@ -157,6 +157,15 @@ int s2s_nhwc_to_nchw(int dtype, const void* x, int ldx, float* y_nchw, int accum
  * out: float [B][3][S][S]. */
 int s2s_paired_crop_flip_normalize(const void* src_u8, const void* tgt_u8, const int* params, float* out_src,
                                    float* out_tgt, int B, int Hs, int Ws, int S, void* stream);
+/* The use_augmentation=False branch (paired_data_module.py:200-211): TF.resize on a PIL image =
+ * PIL.Image.resize((Wo, Ho), BILINEAR) -- Pillow's two-pass 22-bit fixed-point resampler with a uint8 intermediate
+ * (Pillow src/libImaging/Resample.c) -- then to_tensor and Normalize(0.5, 0.5).  The coefficient tables (bounds:
+ * int32 [out][2] = first input index, tap count; kk: int32 [out][ksize]) are Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc, built on the host (stain2stain_amd/data.py).  src: uint8 [B][Hs][Ws][3]; tmp: uint8
+ * [B][Hs][Wo][3] scratch; out_u8 (optional): uint8 [B][Ho][Wo][3]; out_f (optional): float [B][3][Ho][Wo]. */
+int s2s_pil_resize_bilinear_normalize(const void* src_u8, void* tmp_u8, const int* bounds_h, const int* kk_h,
+                                      int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v, void* out_u8,
+                                      float* out_f, int B, int Hs, int Ws, int Ho, int Wo, void* stream);
 
 /* ---- segmentation loss (seg_loss.hip) -- SURVEY section 8 row f2 --------------------------------------
  * seg = dw * DiceLoss(sigmoid(z), g) + (1-dw) * BCEWithLogits(z, g)  (conditional_flow_matching_multitask.py:36-53,

@@ -12,6 +12,9 @@ from typing import Optional, Tuple
 
 import torch
 
+import math
+from functools import lru_cache
+
 from . import _native, ops
 
 
@@ -51,3 +54,69 @@ def paired_crop_flip_normalize(src_u8: torch.Tensor, tgt_u8: torch.Tensor, param
                                                       ops._stream())
     _native.check(rc, "paired_crop_flip_normalize")
     return out_s, out_t
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the use_augmentation=False branch: TF.resize on a PIL image + to_tensor + Normalize
+# ----------------------------------------------------------------------------------------------------------------
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+@lru_cache(maxsize=64)
+def pil_bilinear_tables(in_size: int, out_size: int):
+    """Pillow's resampling windows for one axis: (bounds int32 [out, 2], kk int32 [out, ksize], ksize), built as
+    Resample.c builds them (precompute_coeffs in double precision with the triangle filter of support
+    max(in/out, 1), normalize_coeffs_8bpc to 22-bit fixed point)."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    bounds, kk = [], []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - a if a < 1.0 else 0.0)
+        ww = 0.0
+        for v in w:
+            ww += v
+        row = [0] * ksize
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            v = k * (1 << _PIL_PRECISION_BITS)
+            row[x] = int(-0.5 + v) if k < 0 else int(0.5 + v)
+        bounds.append([xmin, xmax])
+        kk.append(row)
+    return (torch.tensor(bounds, dtype=torch.int32), torch.tensor(kk, dtype=torch.int32), ksize)
+
+
+def resize_normalize(img_u8: torch.Tensor, size: int, want_u8: bool = False):
+    """uint8 [B, H, W, 3] on the GPU -> float32 [B, 3, size, size] = Normalize(to_tensor(PIL resize BILINEAR));
+    with ``want_u8`` also the resized uint8 [B, size, size, 3] image."""
+    if img_u8.dtype != torch.uint8 or not img_u8.is_cuda or img_u8.dim() != 4 or img_u8.shape[3] != 3:
+        raise RuntimeError("stain2stain_amd: expected a uint8 [B,H,W,3] tensor on the GPU")
+    B, H, W, _ = img_u8.shape
+    dev = img_u8.device
+    img_u8 = img_u8.contiguous()
+    bh = kh = bv = kv = None
+    ksh = ksv = 0
+    tmp = None
+    if W != size:
+        bh, kh, ksh = pil_bilinear_tables(W, size)
+        bh, kh = bh.to(dev), kh.to(dev)
+        tmp = torch.empty((B, H, size, 3), dtype=torch.uint8, device=dev)
+    if H != size:
+        bv, kv, ksv = pil_bilinear_tables(H, size)
+        bv, kv = bv.to(dev), kv.to(dev)
+    out_f = torch.empty((B, 3, size, size), dtype=torch.float32, device=dev)
+    out_u8 = torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    ptr = lambda t: 0 if t is None else t.data_ptr()      # noqa: E731
+    rc = _native.lib().s2s_pil_resize_bilinear_normalize(img_u8.data_ptr(), ptr(tmp), ptr(bh), ptr(kh), ksh, ptr(bv),
+                                                         ptr(kv), ksv, ptr(out_u8), out_f.data_ptr(), B, H, W, size,
+                                                         size, ops._stream())
+    _native.check(rc, "pil_resize_bilinear_normalize")
+    return (out_f, out_u8) if want_u8 else out_f

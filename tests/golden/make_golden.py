@@ -427,6 +427,34 @@ def make_variants_fixture():
     print("variants_step.npz", {k: float(out[k]) for k in ("mse/loss", "roi/loss", "charb/value")})
 
 
+def make_input_fixture():
+    """Row f1.  torchvision (absent) dispatches TF.crop / TF.hflip / TF.vflip / TF.resize on PIL images to Pillow's
+    own Image.crop / Image.transpose / Image.resize(BILINEAR); Pillow is installed, so its outputs are the vectors.
+    to_tensor / Normalize are applied with the documented formulas (uint8/255, (x-0.5)/0.5) in torch."""
+    from PIL import Image
+    rng = np.random.default_rng(SEED + 9)
+    out = {}
+    # use_augmentation branch (paired_data_module.py:170-199): crop window + flips
+    img = rng.integers(0, 256, (80, 96, 3), dtype=np.uint8)
+    out["aug/img"] = img
+    cases = [(3, 7, 0, 0), (16, 32, 1, 0), (0, 0, 0, 1), (11, 29, 1, 1)]
+    out["aug/params"] = np.array(cases, dtype=np.int32)
+    for i, (top, left, hf, vf) in enumerate(cases):
+        im = Image.fromarray(img, "RGB").crop((left, top, left + 64, top + 64))     # TF.crop(img, top, left, 64, 64)
+        if hf:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)                                # TF.hflip
+        if vf:
+            im = im.transpose(Image.FLIP_TOP_BOTTOM)                                # TF.vflip
+        out[f"aug/out{i}"] = np.asarray(im)
+    # no-augmentation branch (:200-211): TF.resize(img, (S, S)) == img.resize((S, S), Image.BILINEAR)
+    for i, (h, w, s_) in enumerate([(128, 128, 64), (75, 70, 64), (50, 47, 64), (64, 90, 64), (33, 64, 64)]):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out[f"resize/in{i}"] = im
+        out[f"resize/out{i}"] = np.asarray(Image.fromarray(im, "RGB").resize((s_, s_), Image.BILINEAR))
+    np.savez_compressed(os.path.join(OUT, "input_pipeline.npz"), **out)
+    print("input_pipeline.npz", len(out), "arrays (Pillow", Image.__version__ + ")")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
@@ -438,3 +466,4 @@ if __name__ == "__main__":
     make_multiclass_fixture()
     make_checkpoint_fixture()
     make_variants_fixture()
+    make_input_fixture()
