@@ -134,6 +134,11 @@ int s2s_cfm_sample(const float* x0, const float* x1, const float* t, const float
 /* loss = mean((v-u)^2) (conditional_flow_matching.py:72); dv optional; work: double[1024] */
 int s2s_mse_loss(const float* v, const float* u, float* dv, float grad_scale, float* loss, double* work, long count,
                  void* stream);
+/* Scaled RMS error of an embedded Runge-Kutta step, the step-size control of the adaptive sampler that stands in for
+ * torchdyn's dopri5 (conditional_flow_matching.py:157-170): out[0] = sqrt(mean((e / (atol + rtol max(|y0|,|y1|)))^2));
+ * work: double[1024]. */
+int s2s_ode_error_norm(const float* e, const float* y0, const float* y1, float atol, float rtol, float* out,
+                       double* work, long n, void* stream);
 int s2s_axpy(float* x, const float* y, float a, long n, void* stream);
 int s2s_fill_f32(float* x, float v, long n, void* stream);
 

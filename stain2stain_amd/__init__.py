@@ -9,12 +9,12 @@ from .components import (ClassConditionalFlowUNet, FlowMatchingDecoder, FlowUNet
 from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowMatcher,
                             ConditionalFlowMatchingModule, MaskConditionedFlowMatchingModule,
                             MultiTaskFlowMatchingModule, ROICharbonnierFlowMatchingModule,
-                            ROIWeightedFlowMatchingModule, euler_generate)
+                            ROIWeightedFlowMatchingModule, dopri5_generate, euler_generate)
 from . import checkpoint
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
-           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate",
+           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate",
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint"]

@@ -141,6 +141,40 @@ __global__ __launch_bounds__(256) void mse_finalize_kernel(const double* part, i
   if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
 }
 
+// Scaled error norm of an embedded Runge-Kutta step (the step-size control of the adaptive sampler):
+//   part[blk] = sum over elements of (e / (atol + rtol * max(|y0|, |y1|)))^2
+__global__ __launch_bounds__(256) void ode_err_partial_kernel(const float* __restrict__ e, const float* __restrict__ y0,
+                                                              const float* __restrict__ y1, float atol, float rtol,
+                                                              long n, double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float sc = atol + rtol * fmaxf(fabsf(y0[i]), fabsf(y1[i]));
+    const float r = e[i] / sc;
+    s += (double)r * (double)r;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ode_err_finalize_kernel(const double* part, int nblk, double inv_n, float* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)sqrt(red[0] * inv_n);
+}
+
 __global__ void axpy_kernel(f32x4* __restrict__ x, const f32x4* __restrict__ y, float a, long total4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
     x[i] += a * y[i];
@@ -231,6 +265,20 @@ extern "C" int s2s_mse_loss(const float* v, const float* u, float* dv, float gra
   hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, (const f32x4*)v, (const f32x4*)u, (f32x4*)dv,
                      (float)(2.0 * (double)grad_scale / (double)count), count / 4, work);
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, s, work, nb, 1.0 / (double)count, loss);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// out[0] = sqrt(mean((e / (atol + rtol * max(|y0|, |y1|)))^2)); work: double[1024]
+extern "C" int s2s_ode_error_norm(const float* e, const float* y0, const float* y1, float atol, float rtol,
+                                  float* out, double* work, long n, void* stream) {
+  if (!e || !y0 || !y1 || !out || !work) return S2S_ERR_NULL;
+  if (n <= 0) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  int nb = ew_grid(n);
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  hipLaunchKernelGGL(ode_err_partial_kernel, dim3(nb), dim3(256), 0, s, e, y0, y1, atol, rtol, n, work);
+  hipLaunchKernelGGL(ode_err_finalize_kernel, dim3(1), dim3(256), 0, s, work, nb, 1.0 / (double)n, out);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

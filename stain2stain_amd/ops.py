@@ -518,6 +518,14 @@ def class_embed_bwd(dout: torch.Tensor, y: torch.Tensor, num_classes: int) -> to
     return dtable
 
 
+def ode_error_norm(e: torch.Tensor, y0: torch.Tensor, y1: torch.Tensor, atol: float, rtol: float) -> torch.Tensor:
+    out = torch.empty((1,), dtype=torch.float32, device=e.device)
+    work = torch.empty((1024,), dtype=torch.float64, device=e.device)
+    _native.check(_L().s2s_ode_error_norm(_f32(e), _f32(y0), _f32(y1), float(atol), float(rtol), _f32(out),
+                                          work.data_ptr(), e.numel(), _stream()), "ode_error_norm")
+    return out
+
+
 def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:
     _native.check(_L().s2s_axpy(_f32(x), _f32(y), float(a), x.numel(), _stream()), "axpy")
 

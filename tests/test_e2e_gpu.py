@@ -266,3 +266,35 @@ def test_reference_scheduler_drives_the_fused_trainer():
     tr.optimizer.step()                                     # the handle's step() is the trainer's optimiser step
     step2 = float((w.detach() - before).abs().max())
     assert step2 < 0.3 * step1
+
+
+def test_dopri5_sampler_matches_scipy_rk45_on_the_oracle():
+    """The adaptive sampler (stand-in for torchdyn's dopri5, which is absent) against scipy's RK45 -- the same
+    Dormand-Prince pair and step control -- integrating the CPU oracle's eval-mode network; and against a fine
+    fixed-step Euler solve.  Tolerances of the solve: atol = rtol = 1e-4 as in the reference's generate()."""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    from oracle import unet_oracle as O
+    from stain2stain_amd import FlowUNet, dopri5_generate, euler_generate
+    from conftest import load_golden
+    G = load_golden("tiny_step.npz")
+    P = sub(G, "step1/after/")
+    net = FlowUNet(3, [16, 32], 3, 32, precision="fp32")
+    net.load_state_dict(P)
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+
+    def f(t, yv):
+        xx = torch.from_numpy(yv.reshape(2, 3, 16, 16)).float()
+        with torch.no_grad():
+            v = O.flow_forward(torch.full((2,), float(t)), xx, P, False)
+        return v.double().numpy().reshape(-1)
+
+    sol = solve_ivp(f, (0.0, 1.0), x.double().numpy().reshape(-1), method="RK45", rtol=1e-4, atol=1e-4)
+    want = torch.from_numpy(sol.y[:, -1].reshape(2, 3, 16, 16)).float()
+    got, stats = dopri5_generate(net, x.to(DEV), atol=1e-4, rtol=1e-4, return_stats=True)
+    assert float((got.cpu() - want).abs().max()) < 2e-3 * float(want.abs().max())
+    assert stats["accepted"] + stats["rejected"] == (sol.nfev - 2) // 6     # same number of attempted steps
+    fine = euler_generate(net, x.to(DEV), 400).cpu()
+    assert float((got.cpu() - fine).abs().max()) < 2e-2 * float(fine.abs().max())
