@@ -74,3 +74,19 @@ def test_single_process_bucketer_is_a_noop():
     bk = GradBucketer(flat, [4, 6])
     bk.start_step(); bk.mark_ready(1); bk.wait_all()
     assert not bk.enabled and bk.grad_scale == 1.0 and torch.equal(flat, torch.ones(10))
+
+
+def test_production_bucket_plan_leaves_only_the_stem_for_the_end():
+    """Backward-completion order of the production net: the big gradients (decoder ups.0, encoder downs.3) close their
+    buckets mid-backward; what has to wait for the very last layer is the stem's 0.1 MB."""
+    from stain2stain_amd import FlowUNet
+    from stain2stain_amd.ddp import plan_buckets
+    from stain2stain_amd.trainer import _param_groups
+    net = FlowUNet()
+    groups = _param_groups(net)
+    sizes = [sum((p.numel() + 7) // 8 * 8 for _, _, p in g) for g in groups]
+    assert sum(p.numel() for g in groups for _, _, p in g) == sum(p.numel() for p in net.parameters()) == 31_785_603
+    buckets = plan_buckets(sizes, int(4.0 * (1 << 20) / 4))
+    mb = [round((hi - lo) * 4 / 2 ** 20, 1) for _, lo, hi in buckets]
+    assert len(buckets) == 6 and mb[-1] < 0.2 and max(mb) > 50
+    assert buckets[-1][0] == len(sizes) - 1 and buckets[0][1] == 0 and buckets[-1][2] == sum(sizes)
