@@ -66,6 +66,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (default: the headline 16)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--tile", type=int, default=TILE, help="tile edge (default 256; 512 = BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true",
                     help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
@@ -77,6 +78,7 @@ def main() -> None:
                     help="PCIe-inclusive variant for DESIGN.md: every step copies a fresh uint8 batch from pinned host "
                          "memory and runs the GPU crop/flip/normalise kernel before the optimisation step")
     args = ap.parse_args()
+    globals()["TILE"] = args.tile
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,7 +220,7 @@ def main() -> None:
         # runs of this same command, gfx950 correction applied); the committed summary is read back here
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_current.json")
-        if os.path.exists(tpath) and args.batch == BATCH_PER_GPU and args.precision == "bf16":
+        if os.path.exists(tpath) and args.batch == BATCH_PER_GPU and args.precision == "bf16" and TILE == 256:
             try:
                 tj = json.load(open(tpath))
                 traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in tj.items() if k.startswith("conv3x3_mfma"))
@@ -230,7 +232,7 @@ def main() -> None:
                        **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {})}
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         out = {
-            "metric": "paired 256x256 stain tiles/sec (full CFM optimisation step)",
+            "metric": f"paired {TILE}x{TILE} stain tiles/sec (full CFM optimisation step)",
             "value": round(B * world * args.steps / elapsed, 3),
             "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +240,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic" + (" (uint8 tiles copied from pinned host memory every step)"
                                                            if args.h2d else ""),
-            "config": {"workload": "CFM U-Net [64,128,256,512,1024] 3x256x256 H&E->IHC tiles, "
+            "config": {"workload": f"CFM U-Net [64,128,256,512,1024] 3x{TILE}x{TILE} H&E->IHC tiles, "
                                    f"batch {B}/GPU, sample+fwd+loss+bwd+allreduce+Adam",
                        "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
                        "final_loss": round(float(loss), 6)},
