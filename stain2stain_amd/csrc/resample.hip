@@ -117,6 +117,23 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
       if (x_lo < 0) x_lo = 0;
       if (x_hi > Wu - 1) x_hi = Wu - 1;
     }
+    // column candidates once per source pixel (they were re-derived for every contributing row): slot j = ux - x_lo,
+    // weight 0 = does not read this source column / outside the padded output
+    constexpr int NSLOT = 12;                         // the bracket holds at most 2/scale + 5 <= 11 candidates
+    float wxs[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int ux = x_lo + j;
+      float wx = 0.f;
+      if (ux <= x_hi) {
+        const Axis ax = ac_axis(ux, Win, sw);
+        if (ax.i0 == ix) wx += ax.w0;
+        if (ax.i1 == ix) wx += ax.w1;
+        const int ox = ux + padL;
+        if (ox < 0 || ox >= Wout) wx = 0.f;
+      }
+      wxs[j] = wx;
+    }
     f32x8 acc;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
@@ -127,15 +144,12 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
       if (ay.i1 == iy) wy += ay.w1;
       const int oy = uy + padT;
       if (wy == 0.f || oy < 0 || oy >= Hout) continue;
-      for (int ux = x_lo; ux <= x_hi; ++ux) {
-        const Axis ax = ac_axis(ux, Win, sw);
-        float wx = 0.f;
-        if (ax.i0 == ix) wx += ax.w0;
-        if (ax.i1 == ix) wx += ax.w1;
-        const int ox = ux + padL;
-        if (wx == 0.f || ox < 0 || ox >= Wout) continue;
-        const f32x8 g = load8(dy + (((long)n * Hout + oy) * Wout + ox) * lddy + c8);
-        const float w = wy * wx;
+      const T* const rowp = dy + (((long)n * Hout + oy) * Wout + x_lo + padL) * lddy + c8;
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) {
+        if (wxs[j] == 0.f) continue;
+        const f32x8 g = load8(rowp + (long)j * lddy);
+        const float w = wy * wxs[j];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc.v[k] += w * g.v[k];
       }
