@@ -611,19 +611,21 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// `tid` is the thread's index inside its group of 256 (a whole workgroup, or one half of a ping-pong workgroup),
+// `smem` that group's staging area, `stat_row` the tile's row in stat_part; the barriers are workgroup-wide.
 template <int TH, int TW, int BN, int WM, int WN, int LDS_MAIN, bool AFFINE>
 __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
                                                 const float (&bias)[(BN / WN) / 16][4], char* smem, int img, int y0,
-                                                int x0p, int n0) {
+                                                int x0p, int n0, int tid, long stat_row) {
   using T = bf16_t;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   T* __restrict__ yout = static_cast<T*>(a.y);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int cl = lane & 15, q = lane >> 4;
   constexpr int RS = BN * 2 + 16;                          // row stride 4 (mod 64) dwords: 8-byte writes 2-way at worst
   constexpr int CPR = BN / 8, RG = 256 / CPR;              // 16-byte pieces per pixel row, row groups of the read-back
-  constexpr int RED = RG * 2 * BN * 4;                     // per-row-group partial sums
+  constexpr int RED = 4 * 2 * BN * 4;                      // per-wave partial sums
   constexpr int EP = (BM * RS + RED <= LDS_MAIN) ? 1 : ((BM / 2) * RS + RED <= LDS_MAIN ? 2 : 4);
   static_assert(WM % EP == 0 || EP == 1, "epilogue passes split the wave rows");
   static_assert((BM / EP) * RS + RED <= LDS_MAIN, "epilogue staging fits the main-loop LDS");
@@ -695,21 +697,26 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
     }
   }
   if (want_stats) {
-    // red[rg][which][BN]; channels past Cout hold zeros (their rows were skipped above) and are not written out
+    // the 64 / CPR row groups of a wave are folded with shuffles, then red[wave][which][BN] across the four waves;
+    // channels past Cout hold zeros (their rows were skipped above) and are not written out
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      red[(rg * 2 + 0) * BN + c * 8 + k] = s1[k];
-      red[(rg * 2 + 1) * BN + c * 8 + k] = s2[k];
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int m = CPR; m < 64; m <<= 1) { s1[k] += __shfl_xor(s1[k], m, 64); s2[k] += __shfl_xor(s2[k], m, 64); }
+    if (lane < CPR) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(wave * 2 + 0) * BN + c * 8 + k] = s1[k];
+        red[(wave * 2 + 1) * BN + c * 8 + k] = s2[k];
+      }
     }
     lds_barrier();
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, nl = i - which * BN;
-      if (n0 + nl < a.Cout) {
-        float sum = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < RG; ++k) sum += red[(k * 2 + which) * BN + nl];
-        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = sum;
-      }
+      if (n0 + nl < a.Cout && stat_row >= 0)
+        a.stat_part[(stat_row * 2 + which) * a.Cout + n0 + nl] =
+            (red[(0 * 2 + which) * BN + nl] + red[(1 * 2 + which) * BN + nl]) +
+            (red[(2 * 2 + which) * BN + nl] + red[(3 * 2 + which) * BN + nl]);
     }
   }
 }
@@ -866,8 +873,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     });
   }
   if (a.dbg & 16) return;
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0);
-  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0);
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
