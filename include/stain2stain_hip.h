@@ -49,6 +49,11 @@ int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1,
                      const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W, int Cout,
                      void* stream);
 
+/* Diagnostic: with S2S_CONV_DBG=64 in the environment the bf16 kernel's workgroups record the shader-clock counter and
+ * the 100 MHz wall clock at entry and exit; this copies {clk0, clk1, wall0, wall1} of the first n <= 8192 workgroups of
+ * the last launch into a HOST buffer (scripts/clk_probe.py turns them into the MHz the kernel ran at). */
+int s2s_debug_conv_clock(long* out_host, int n);
+
 /* ---- 3x3 convolution weight gradient (conv3x3_wgrad_mfma.hip) -----------------------------------
  * autograd's conv2d weight gradient for the same layers.  part: float[splits][9][Cout][c0+c1] scratch;
  * grad_oihw: float[Cout][c0+c1][3][3], overwritten or accumulated. */

@@ -721,8 +721,13 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
   }
 }
 
+// S2S_CONV_DBG=64: thread 0 of each workgroup records the shader-clock counter and the 100 MHz wall clock at entry
+// and exit (read back with s2s_debug_conv_clock): the clock the kernel actually ran at under its own load.
+__device__ long g_clk[8192 * 4];
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
+  long c0_ = 0, w0_ = 0;
+  if ((a.dbg & 64) && threadIdx.x == 0) { c0_ = __builtin_readcyclecounter(); w0_ = wall_clock64(); }
   using T = bf16_t;
   constexpr int HP = TW + 4, HH_ = TH + 2, ROWS = HH_ * HP;
   constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + 3) / 4;
@@ -875,6 +880,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   if (a.dbg & 16) return;
   if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+  if ((a.dbg & 64) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4 + 0] = c0_; g_clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter(); g_clk[blockIdx.x * 4 + 2] = w0_; g_clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
@@ -1186,6 +1192,15 @@ int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, c
 
 // Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
 // (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.
+// out: HOST buffer long[n][4] = {shader clock at entry, at exit, wall clock (100 MHz) at entry, at exit} of the
+// first n <= 8192 workgroups of the last conv3x3 launch made with S2S_CONV_DBG=64
+extern "C" int s2s_debug_conv_clock(long* out, int n) {
+  if (!out) return S2S_ERR_NULL;
+  if (n <= 0 || n > 8192) return S2S_ERR_SHAPE;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), (size_t)n * 4 * sizeof(long)) == hipSuccess ? S2S_OK
+                                                                                                  : S2S_ERR_LAUNCH;
+}
+
 extern "C" int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
