@@ -77,3 +77,14 @@ def test_product_path_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(root, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_unloadable_library_fails_loudly(tmp_path, monkeypatch):
+    """No silent fallback when the HIP library cannot be loaded: the first op raises and names the file."""
+    from stain2stain_amd import _native
+    bad = tmp_path / "libstain2stain_hip.so"
+    bad.write_bytes(b"not an ELF file")
+    monkeypatch.setattr(_native, "LIB_PATH", str(bad))
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(RuntimeError, match="cannot load"):
+        _native.lib()
