@@ -49,16 +49,6 @@ int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1,
                      const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W, int Cout,
                      void* stream);
 
-/* Data gradient of the second conv of a DoubleConv with the BatchNorm-backward reduction of the block's FIRST
- * conv -> BN -> ReLU layer folded into the epilogue (the gradient tile is in registers there anyway):
- * dx = conv3x3(dy, Wd) as above, and part[s2s_conv3x3_stat_blocks(dtype,B,H,W,Cin)][2][Cin] receives
- * (sum dz, sum dz*xhat), dz = dx * [z*scale+shift > 0], xhat = (z-mean)*invstd, z = the first layer's saved conv
- * output (shared_encoder.py:12-24: the autograd of BatchNorm2d + ReLU).  bf16 only; s2s_conv3x3_bnbwd_supported tells. */
-int s2s_conv3x3_bnbwd_supported(int dtype);
-int s2s_conv3x3_dgrad_bnbwd_nhwc(int dtype, const void* dy, int lddy, int Cdy, const void* wd_packed, void* dx, int lddx,
-                                 float* part, const void* z, int ldz, const float* scale, const float* shift,
-                                 const float* mean, const float* invstd, int B, int H, int W, int Cin, void* stream);
-
 /* Diagnostic: with S2S_CONV_DBG=64 in the environment the bf16 kernel's workgroups record the shader-clock counter and
  * the 100 MHz wall clock at entry and exit; this copies {clk0, clk1, wall0, wall1} of the first n <= 8192 workgroups of
  * the last launch into a HOST buffer (scripts/clk_probe.py turns them into the MHz the kernel ran at). */
@@ -123,13 +113,6 @@ int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldg
                     const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                     float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx, float* work, int B, int H,
                     int W, int C, void* stream);
-
-/* Same backward when the reduction pass was already done by the producer of g1 (s2s_conv3x3_dgrad_bnbwd_nhwc):
- * part: float[nrows][2][C] partials (scratch); work: float[2*C]. */
-int s2s_bn_relu_bwd_from_partials(int dtype, const void* g1, int ldg1, const float* scale, const float* shift,
-                                  const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
-                                  float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx,
-                                  float* part, int nrows, float* work, int B, int H, int W, int C, void* stream);
 
 /* ---- bilinear x2, align_corners=True (+ F.pad to the skip size) (resample.hip) --------------------
  * nn.Upsample + F.pad of Up.forward (task_decoders.py:34,42-47); bias_nc (optional, float[B][C]) is added

@@ -44,15 +44,6 @@ struct Conv3x3Args {
   int ld0, c0, ld1, c1, ldy;
   int B, H, W, Cout, tilesY, tilesX, nchunk;
   int relu;
-  // optional fused BatchNorm-backward reduction (16x16x32 bf16 kernel only): the output tile is the gradient reaching
-  // the ReLU of a conv -> BN -> ReLU layer whose saved conv output is bnb_x; stat_part then receives that layer's
-  // per-channel (sum dz, sum dz * xhat) partials instead of (sum y, sum y^2)
-  const void* bnb_x;
-  int bnb_ld;
-  const float* bnb_scale;
-  const float* bnb_shift;
-  const float* bnb_mean;
-  const float* bnb_invstd;
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
 };
 
@@ -655,21 +646,6 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
       esh[ni][j] = (AFFINE && nok) ? a.ep_shift[n] : 0.f;
     }
   const int c = tid % CPR, rg = tid / CPR;                 // read-back: fixed 8-channel piece, rows rg, rg+RG, ...
-  // fused BatchNorm-backward reduction: the tile is the gradient g reaching a ReLU; with the layer's saved conv output
-  // x:  dz = g * [x*scale+shift > 0],  partials (sum dz, sum dz * (x-mean)*invstd)  -- the expressions of
-  // bn_relu_bwd_reduce_flat_kernel (norm_act.hip), taken here from the stored bf16 gradient like that kernel does
-  const bool bnb = a.bnb_x != nullptr;
-  const T* __restrict__ bnx = static_cast<const T*>(a.bnb_x);
-  float bsc[8], bsh[8], bmu[8], bis[8];
-  if (bnb) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int n = n0 + c * 8 + k;
-      const bool nok = n < a.Cout;
-      bsc[k] = nok ? a.bnb_scale[n] : 0.f; bsh[k] = nok ? a.bnb_shift[n] : 0.f;
-      bmu[k] = nok ? a.bnb_mean[n] : 0.f;  bis[k] = nok ? a.bnb_invstd[n] : 0.f;
-    }
-  }
   float s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
@@ -710,22 +686,11 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
         if (!(a.dbg & 8))
           *reinterpret_cast<bf16x8*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
         if (want_stats) {
-          if (bnb) {
-            const bf16x8 zx = *reinterpret_cast<const bf16x8*>(bnx + (((long)img * a.H + gy) * a.W + gx) * a.bnb_ld + n);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float z = (float)zx[k];
-              const float dz = fmaf(z, bsc[k], bsh[k]) > 0.f ? (float)val[k] : 0.f;
-              s1[k] += dz;
-              s2[k] += dz * ((z - bmu[k]) * bis[k]);
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float t = (float)val[k];
-              s1[k] += t;
-              s2[k] = fmaf(t, t, s2[k]);
-            }
+          for (int k = 0; k < 8; ++k) {
+            const float t = (float)val[k];
+            s1[k] += t;
+            s2[k] = fmaf(t, t, s2[k]);
           }
         }
       }
@@ -1162,12 +1127,6 @@ int select_cfg(int dtype, int B, int H, int W, int Cout) {
   return best;
 }
 
-// 16 = LDS-DMA loop on v_mfma_f32_16x16x32_bf16 (default), 1/3 = the 32x32x16 form with a 4/3-slot ring, 0 = v1
-inline int conv_path() {
-  static const int v = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
-  return v;
-}
-
 int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
   const int id = select_cfg(dtype, a.B, a.H, a.W, a.Cout);
   if (dtype == S2S_F32) {
@@ -1175,7 +1134,8 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
     if (id == 1) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
     return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
   }
-  const int use_dma = conv_path();
+  // 16 = LDS-DMA loop on v_mfma_f32_16x16x32_bf16 (default), 1/3 = the 32x32x16 form with a 4/3-slot ring, 0 = v1
+  static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
   if (use_dma == 16) {
     switch (id) {
       case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
@@ -1222,7 +1182,6 @@ int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, c
   Conv3x3Args a;
   a.x0 = a.x1 = a.w = nullptr; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = a.ep_shift = nullptr;
-  a.bnb_x = nullptr; a.bnb_ld = 0; a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
   a.ld0 = a.c0 = a.ld1 = a.c1 = 0; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = 1; a.relu = 0; a.dbg = 0;
   a.tilesX = a.tilesY = 0;
@@ -1263,7 +1222,6 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift;
-  a.bnb_x = nullptr; a.bnb_ld = 0; a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
@@ -1271,32 +1229,4 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   return dispatch(dtype, a, s);
-}
-
-// 1 when s2s_conv3x3_dgrad_bnbwd_nhwc is available for this dtype in this process (bf16 on the 16x16x32 LDS-DMA path)
-extern "C" int s2s_conv3x3_bnbwd_supported(int dtype) { return dtype == S2S_BF16 && conv_path() == 16 ? 1 : 0; }
-
-// Data gradient of a 3x3 conv whose input was the ReLU output of a conv -> BatchNorm(train) -> ReLU layer, with that
-// layer's BatchNorm-backward reduction folded into the epilogue: dx = conv3x3(dy, Wd) as s2s_conv3x3_nhwc computes it,
-// and part[blocks][2][Cin] (blocks = s2s_conv3x3_stat_blocks(dtype, B, H, W, Cin)) receives the per-channel partial sums
-// (sum dz, sum dz * xhat), dz = dx * [z*scale+shift > 0], xhat = (z-mean)*invstd, z = that layer's saved conv output --
-// what s2s_bn_relu_bwd would otherwise re-read dx and z to compute (feed them to s2s_bn_relu_bwd_from_partials).
-extern "C" int s2s_conv3x3_dgrad_bnbwd_nhwc(int dtype, const void* dy, int lddy, int Cdy, const void* wd_packed, void* dx,
-                                            int lddx, float* part, const void* z, int ldz, const float* scale,
-                                            const float* shift, const float* mean, const float* invstd, int B, int H,
-                                            int W, int Cin, void* stream) {
-  if (!dy || !wd_packed || !dx || !part || !z || !scale || !shift || !mean || !invstd) return S2S_ERR_NULL;
-  if (!s2s_conv3x3_bnbwd_supported(dtype)) return S2S_ERR_DTYPE;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cdy <= 0 || (Cdy % 8) || (Cin % 8) || (lddy % 8) || (lddx % 8) || (ldz % 8))
-    return S2S_ERR_SHAPE;
-  if (((uintptr_t)dy & 15) || ((uintptr_t)wd_packed & 15) || ((uintptr_t)z & 15)) return S2S_ERR_ALIGN;
-  Conv3x3Args a;
-  a.x0 = dy; a.x1 = nullptr; a.w = wd_packed; a.bias = nullptr; a.y = dx; a.stat_part = part;
-  a.ep_scale = a.ep_shift = nullptr;
-  a.bnb_x = z; a.bnb_ld = ldz; a.bnb_scale = scale; a.bnb_shift = shift; a.bnb_mean = mean; a.bnb_invstd = invstd;
-  a.ld0 = lddy; a.c0 = Cdy; a.ld1 = 8; a.c1 = 0; a.ldy = lddx;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cin; a.nchunk = cdiv(Cdy, 32); a.relu = 0;
-  a.tilesX = a.tilesY = 0;
-  a.dbg = 0;
-  return dispatch(dtype, a, static_cast<hipStream_t>(stream));
 }

@@ -674,36 +674,3 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
-
-// BatchNorm+ReLU backward of a layer whose reduction pass was already done by the producer of g1
-// (s2s_conv3x3_dgrad_bnbwd_nhwc): part[nrows][2][C] holds (sum dz, sum dz*xhat) partials (scratch, reduced in place).
-// Finalize (dgamma, dbeta, means) + apply pass only.  work: float[2*C].  The conv-bias gradient is written as its
-// exact value 0 (see s2s_bn_relu_bwd).
-extern "C" int s2s_bn_relu_bwd_from_partials(int dtype, const void* g1, int ldg1, const float* scale, const float* shift,
-                                             const void* x, int ldx, const float* mean, const float* invstd,
-                                             const float* gamma, float* dgamma, float* dbeta, float* dbias_conv,
-                                             int accumulate, void* dx, int lddx, float* part, int nrows, float* work,
-                                             int B, int H, int W, int C, void* stream) {
-  if (!g1 || !scale || !shift || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx || !part || !work)
-    return S2S_ERR_NULL;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) || (ldg1 % 8) || nrows <= 0)
-    return S2S_ERR_SHAPE;
-  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
-  hipStream_t s = (hipStream_t)stream;
-  float* c1 = work;
-  float* c2 = work + C;
-  const double count = (double)B * H * W;
-  const int nb = red_blocks(B, H, W, C);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, prereduce(part, nrows, 2 * C, s),
-                     C, count, dgamma, dbeta, accumulate, c1, c2, (dbias_conv && !accumulate) ? dbias_conv : nullptr);
-  dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(bn_relu_bwd_apply_flat_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g1, ldg1, scale,
-                       shift, (const bf16_t*)x, ldx, mean, invstd, gamma, c1, c2, (bf16_t*)dx, lddx, nullptr,
-                       (long)B * H * W, C);
-  else
-    hipLaunchKernelGGL(bn_relu_bwd_apply_flat_kernel<float>, grid, dim3(256), 0, s, (const float*)g1, ldg1, scale, shift,
-                       (const float*)x, ldx, mean, invstd, gamma, c1, c2, (float*)dx, lddx, nullptr, (long)B * H * W, C);
-  S2S_LAUNCH_CHECK();
-  return S2S_OK;
-}

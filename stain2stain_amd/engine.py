@@ -169,19 +169,14 @@ def _g(grads: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
         raise RuntimeError(f"stain2stain_amd: no gradient buffer for parameter {name!r}") from e
 
 
-def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool, need_dx: bool, stem: bool = False,
-                      pre_part=None, fuse_prev: Optional[LayerCtx] = None):
-    """Backward of conv -> BN -> ReLU.  g1/gp: gradient wrt the activation / wrt its 2x2 max-pool.
-    ``fuse_prev``: the layer that produced this conv's input (first conv of the same DoubleConv); its BatchNorm-backward
-    reduction is then folded into this layer's data-gradient kernel and returned as the second value, to be passed as
-    ``pre_part`` to that layer's own backward.  Returns dx, or (dx, partials) with ``fuse_prev``."""
+def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool, need_dx: bool, stem: bool = False):
+    """Backward of conv -> BN -> ReLU.  g1/gp: gradient wrt the activation / wrt its 2x2 max-pool."""
     p = cb.prefix
     i_conv, i_bn = cb.idx
     dgamma = _g(grads, f"{p}.{i_bn}.weight")
     dbeta = _g(grads, f"{p}.{i_bn}.bias")
     dbias = _g(grads, f"{p}.{i_conv}.bias") if cb.conv.bias is not None else None
-    draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate,
-                           pre_part=pre_part)
+    draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
     dw = _g(grads, f"{p}.{i_conv}.weight")
     if stem:
         ops.stem_wgrad(draw, lc.x0, dw, None, accumulate)
@@ -189,11 +184,6 @@ def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool,
     ops.conv3x3_wgrad(draw, lc.x0, lc.x1, dw, accumulate)
     if not need_dx:
         return None
-    if fuse_prev is not None:
-        if lc.x1 is None and ops.bnbwd_fusion_available(draw.dtype):
-            return ops.conv3x3_dgrad_bnbwd(draw, cb.packed(draw.dtype)[1], cb.cin, fuse_prev.raw, fuse_prev.stats)
-        dx, _ = ops.conv3x3(draw, None, cb.packed(draw.dtype)[1], None, cb.cin)
-        return dx, None
     dx, _ = ops.conv3x3(draw, None, cb.packed(draw.dtype)[1], None, cb.cin)
     return dx
 
@@ -229,9 +219,8 @@ def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeat
         g1 = dfeats[l]
         if g1 is None and gpool is None:
             raise RuntimeError("stain2stain_amd: encoder level without any incoming gradient")
-        ga1, part1 = _conv_bn_relu_bwd(c2, lc2, g1, gpool, grads, accumulate, need_dx=True, fuse_prev=lc1)
-        gpool = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=(l > 0), stem=(l == 0),
-                                  pre_part=part1)
+        ga1 = _conv_bn_relu_bwd(c2, lc2, g1, gpool, grads, accumulate, need_dx=True)
+        gpool = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=(l > 0), stem=(l == 0))
         if on_group_done is not None:
             on_group_done(nlev - 1 - l)
 
@@ -284,8 +273,8 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
     for i in range(len(ctx.layers) - 1, -1, -1):
         c1, c2 = dec.up_blocks[i]
         lc1, lc2 = ctx.layers[i]
-        ga1, part1 = _conv_bn_relu_bwd(c2, lc2, g, None, grads, accumulate, need_dx=True, fuse_prev=lc1)
-        dcat = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=True, pre_part=part1)
+        ga1 = _conv_bn_relu_bwd(c2, lc2, g, None, grads, accumulate, need_dx=True)
+        dcat = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=True)
         cs = ctx.skips[i].shape[3]
         dskips[i] = dcat[..., :cs]
         low = ctx.lows[i]

@@ -8,8 +8,6 @@ RuntimeError (the reference's only error convention is Python exceptions, src/ut
 """
 from __future__ import annotations
 
-import os
-
 from typing import Optional, Tuple
 
 import torch
@@ -150,32 +148,6 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
                                _f32(scale), _f32(shift), int(relu), B, H, W, cout, _stream())
     _native.check(rc, "conv3x3")
     return out, stat
-
-
-def bnbwd_fusion_available(dtype: torch.dtype) -> bool:
-    """The data-gradient kernel can fold the previous layer's BatchNorm-backward reduction into its epilogue
-    (bf16 on the default conv path; not when the conv-bias gradient is summed explicitly)."""
-    return bool(_L().s2s_conv3x3_bnbwd_supported(0 if dtype == torch.bfloat16 else 1)) and \
-        os.environ.get("S2S_BN_DBIAS_SUM", "0") == "0" and os.environ.get("S2S_BNBWD_FUSE", "1") != "0"
-
-
-@_timed("conv3x3_mfma", lambda dy, wd_packed, cin, z, stats, **kw: 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cin * 9 * dy.shape[3])
-def conv3x3_dgrad_bnbwd(dy: torch.Tensor, wd_packed: torch.Tensor, cin: int, z: torch.Tensor, stats: torch.Tensor):
-    """dx = conv3x3(dy, Wd) plus the (sum dz, sum dz*xhat) partial rows of the layer whose conv output is ``z`` and
-    whose bn_finalize() output is ``stats``; returns (dx, part[rows, 2, cin])."""
-    B, H, W, cdy = dy.shape
-    pdy, lddy = _nhwc(dy)
-    pz, ldz = _nhwc(z)
-    if z.shape != (B, H, W, cin) or z.dtype != dy.dtype:
-        raise RuntimeError("stain2stain_amd: conv3x3_dgrad_bnbwd: saved conv output does not match the gradient")
-    dx = torch.empty((B, H, W, cin), dtype=dy.dtype, device=dy.device)
-    nb = _L().s2s_conv3x3_stat_blocks(_dt(dy), B, H, W, cin)
-    part = torch.empty((nb, 2, cin), dtype=torch.float32, device=dy.device)
-    rc = _L().s2s_conv3x3_dgrad_bnbwd_nhwc(_dt(dy), pdy, lddy, cdy, wd_packed.data_ptr(), dx.data_ptr(), cin, _f32(part),
-                                           pz, ldz, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
-                                           stats[1].data_ptr(), B, H, W, cin, _stream())
-    _native.check(rc, "conv3x3_dgrad_bnbwd_nhwc")
-    return dx, part
 
 
 @_timed("conv3x3_wgrad_mfma", _wgrad_flops)
@@ -337,25 +309,11 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
 @_timed("bn_relu_bwd")
 def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], x: torch.Tensor,
                 stats: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
-                dbias_conv: Optional[torch.Tensor], accumulate: bool = False,
-                pre_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+                dbias_conv: Optional[torch.Tensor], accumulate: bool = False) -> torch.Tensor:
     """Returns dx (gradient wrt the conv output x).  stats = bn_finalize() output (rows mean, invstd, scale,
-    shift); the ReLU mask / pool winner are recomputed from x with the forward's scale and shift.
-    ``pre_part``: (sum dz, sum dz*xhat) partial rows already produced by conv3x3_dgrad_bnbwd (no pooled gradient)."""
+    shift); the ReLU mask / pool winner are recomputed from x with the forward's scale and shift."""
     B, H, W, C = x.shape
     px, ldx = _nhwc(x)
-    if pre_part is not None:
-        if gp is not None or g1 is None:
-            raise RuntimeError("stain2stain_amd: fused BatchNorm-backward partials need a dense gradient only")
-        p1, ld1 = _nhwc(g1)
-        dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
-        work = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
-        rc = _L().s2s_bn_relu_bwd_from_partials(_dt(x), p1, ld1, stats[2].data_ptr(), stats[3].data_ptr(), px, ldx,
-                                                stats[0].data_ptr(), stats[1].data_ptr(), _f32(gamma), _f32(dgamma),
-                                                _f32(dbeta), _f32(dbias_conv), int(accumulate), dx.data_ptr(), C,
-                                                _f32(pre_part), pre_part.shape[0], _f32(work), B, H, W, C, _stream())
-        _native.check(rc, "bn_relu_bwd_from_partials")
-        return dx
     p1, ld1 = (0, 8) if g1 is None else _nhwc(g1)
     p2, ld2 = (0, 8) if gp is None else _nhwc(gp)
     dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
