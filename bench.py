@@ -32,6 +32,25 @@ BATCH_PER_GPU = 16
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def algorithmic_bytes(batch: int, tile: int) -> dict:
+    """Algorithmic HBM bytes per step of the bandwidth-bound passes (inputs + outputs at their storage
+    width, bf16 activations / fp32 optimiser state) for the production U-Net, keyed like the --breakdown table."""
+    f = FEATURES
+    L = len(f)
+    # BatchNorm'd conv outputs: two per encoder level, two per decoder level
+    enc = sum(2 * f[l] * (tile >> l) ** 2 for l in range(L))
+    dec = sum(2 * f[l] * (tile >> l) ** 2 for l in range(L - 1))
+    bn_elems = batch * (enc + dec)
+    pooled = batch * sum(f[l] * (tile >> (l + 1)) ** 2 for l in range(L - 1))
+    up_out = batch * sum(f[l + 1] * (tile >> l) ** 2 for l in range(L - 1))          # up-sampled tensors (channels of the level below)
+    params = 31_785_603
+    return {"bn_relu_apply": 2 * (2 * bn_elems + pooled), "bn_relu_bwd": 2 * (5 * bn_elems + 2 * pooled),
+            "upsample2x_fwd": 2 * (up_out + up_out // 4), "upsample2x_bwd": 2 * (up_out + up_out // 4),
+            "adam_step_": 28 * params, "pack_conv3x3": (4 + 2 + 2) * params,
+            "head_loss_fused": batch * tile * tile * (2 * 2 * f[0] + 2 * 4 * 3),
+            "cfm_sample": batch * 3 * tile * tile * 4 * 4}
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     """The CPU oracle (a port of the reference's torch path) timed on this box's host cores."""
     from oracle import unet_oracle as O
@@ -228,8 +247,10 @@ def main() -> None:
                 traffic = None
         n_l, t_l, f_l = agg[dom]
         achieved = f_l / t_l / 1e12
+        ab = algorithmic_bytes(B, TILE)
         kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / args.steps, 4),
-                       **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {})}
+                       **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {}),
+                       **({"algorithmic_gb_per_s": round(ab[k] * args.steps / v[1] / 1e9, 0)} if k in ab else {})}
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         out = {
             "metric": f"paired {TILE}x{TILE} stain tiles/sec (full CFM optimisation step)",
