@@ -89,6 +89,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true",
                     help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="bracket the conv launches of every N-th timed step with HIP events for the roofline leg "
+                         "(1 = every step; the marker packets cost ~10 us per bracketed launch)")
     ap.add_argument("--mode", default="train", choices=["train", "sample"],
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
@@ -128,16 +131,21 @@ def main() -> None:
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        ops.profile_start(("conv3x3_mfma",))
+        prof, timed_steps = [], 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            sampled = i % max(1, args.event_every) == 0       # see the note in the training loop below
+            if sampled:
+                ops.profile_start(("conv3x3_mfma",))
             out = euler_generate(net, src, args.euler_steps)
+            if sampled:
+                prof += ops.profile_stop()
+                timed_steps += 1
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        prof = ops.profile_stop()
         if use_dist:
             el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -159,8 +167,8 @@ def main() -> None:
                 "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (forward launches)",
                              "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                             "traffic": None, "launches_per_step": n_l // args.steps,
-                             "avg_launch_ms": round(t_l * 1e3 / n_l, 4)}}), flush=True)
+                             "traffic": None, "launches_per_step": n_l // timed_steps,
+                             "launches_timed": n_l, "avg_launch_ms": round(t_l * 1e3 / n_l, 4)}}), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -209,20 +217,30 @@ def main() -> None:
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    # live HIP-event timing of the dominant kernels only (every launch of the timed region)
-    ops.profile_start(None if args.breakdown else ("conv3x3_mfma", "conv3x3_wgrad_mfma"))
+    # live HIP-event timing of the dominant kernels inside the timed region.  An event pair is two marker packets on
+    # the launch stream (~5 us each side of the kernel, rocprofv3 kernel trace), i.e. ~0.3-0.5 ms per step if all
+    # 51 conv launches of every step are bracketed; so the brackets go around every launch of every
+    # --event-every'th step (default 8; 1 = every step) and the per-launch average is taken over those.
+    every = 1 if args.breakdown else max(1, args.event_every)
+    only = None if args.breakdown else ("conv3x3_mfma", "conv3x3_wgrad_mfma")
+    prof, timed_steps = [], 0
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
         if feed:
             x0, x1 = feed(args.warmup + i)
+        sampled = i % every == 0
+        if sampled:
+            ops.profile_start(only)
         loss = trainer.step(x0, x1, ts[args.warmup + i])
+        if sampled:
+            prof += ops.profile_stop()
+            timed_steps += 1
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ops.profile_stop()
     if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -248,9 +266,9 @@ def main() -> None:
         n_l, t_l, f_l = agg[dom]
         achieved = f_l / t_l / 1e12
         ab = algorithmic_bytes(B, TILE)
-        kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / args.steps, 4),
+        kernels = {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / timed_steps, 4),
                        **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {}),
-                       **({"algorithmic_gb_per_s": round(ab[k] * args.steps / v[1] / 1e9, 0)} if k in ab else {})}
+                       **({"algorithmic_gb_per_s": round(ab[k] * timed_steps / v[1] / 1e9, 0)} if k in ab else {})}
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         out = {
             "metric": f"paired {TILE}x{TILE} stain tiles/sec (full CFM optimisation step)",
@@ -269,7 +287,7 @@ def main() -> None:
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/hbm_traffic_current.json)",
-                         "launches_per_step": n_l // args.steps,
+                         "launches_per_step": n_l // timed_steps, "launches_timed": n_l,
                          "avg_launch_ms": round(t_l * 1e3 / n_l, 4),
                          "algorithmic_gflop_per_launch": round(f_l / n_l / 1e9, 3)},
             "kernels": kernels,
