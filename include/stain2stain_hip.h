@@ -39,8 +39,9 @@ extern "C" {
  * task_decoders.py:15,18.  Input = channels [0,c0) of x0 followed by [0,c1) of x1 (x1 may be NULL with
  * c1 = 0): the torch.cat([skip, up], dim=1) of task_decoders.py:49 without the copy.
  * w_packed: s2s_pack_conv3x3 output (forward layout for the forward pass, dgrad layout + swapped channel
- * roles for the data gradient).  stat_part (optional): float[s2s_conv3x3_stat_blocks()][2][Cout] partial
- * (sum, sum of squares) of the stored values per output channel, for BatchNorm.  ep_scale/ep_shift
+ * roles for the data gradient).  stat_part (optional): float[2][Cout][s2s_conv3x3_stat_blocks()] partial
+ * (sum, sum of squares) of the stored values per output channel and producing workgroup, for BatchNorm
+ * (channel-major, the layout s2s_bn_finalize reads).  ep_scale/ep_shift
  * (optional, both or neither) and relu: y = relu?((acc + bias) * scale + shift) -- eval-mode BatchNorm
  * folded into the epilogue. */
 int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout);

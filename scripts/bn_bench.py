@@ -27,7 +27,7 @@ for H, C in SHAPES:
     gamma, beta = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev)
     rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)
     nblk = B * (H // 8) * max(H // 32, 1)
-    stat = torch.rand(nblk, 2, C, device=dev)
+    stat = torch.rand(2, C, nblk, device=dev)
     st = ops.bn_finalize(stat.clone(), B * H * H, gamma, beta, rm, rv, nbt)
     dg, db, dbias = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     t_fin = timeit(lambda: ops.bn_finalize(stat, B * H * H, gamma, beta, rm, rv, nbt))

@@ -38,7 +38,7 @@ struct Conv3x3Args {
   const void* w;        // packed [nchunk][9][Cout][32]
   const float* bias;    // [Cout] or null
   void* y;
-  float* stat_part;     // [gridDim.x][2][Cout] or null
+  float* stat_part;     // [2][Cout][gridDim.x] (channel-major: the finalize kernel reads each channel's row contiguously) or null
   const float* ep_scale;  // optional epilogue affine (eval-mode BatchNorm folded), [Cout]
   const float* ep_shift;
   int ld0, c0, ld1, c1, ldy;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < WM; ++k) s += red[(k * 2 + which) * BN + nl];
-        a.stat_part[((long)blockIdx.x * 2 + which) * a.Cout + n0 + nl] = s;
+        a.stat_part[((long)which * a.Cout + n0 + nl) * gridDim.x + blockIdx.x] = s;
       }
     }
   }
@@ -714,7 +714,7 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, nl = i - which * BN;
       if (n0 + nl < a.Cout && stat_row >= 0)
-        a.stat_part[(stat_row * 2 + which) * a.Cout + n0 + nl] =
+        a.stat_part[((long)which * a.Cout + n0 + nl) * gridDim.x + stat_row] =
             (red[(0 * 2 + which) * BN + nl] + red[(1 * 2 + which) * BN + nl]) +
             (red[(2 * 2 + which) * BN + nl] + red[(3 * 2 + which) * BN + nl]);
     }
@@ -1191,7 +1191,7 @@ int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, c
 }
 
 // Number of row-blocks of partial statistics the kernel writes for a (B,H,W,Cout) problem
-// (= gridDim.x); the caller sizes stat_part as [blocks][2][Cout] floats.
+// (= gridDim.x); the caller sizes stat_part as [2][Cout][blocks] floats.
 // out: HOST buffer long[n][4] = {shader clock at entry, at exit, wall clock (100 MHz) at entry, at exit} of the
 // first n <= 8192 workgroups of the last conv3x3 launch made with S2S_CONV_DBG=64
 extern "C" int s2s_debug_conv_clock(long* out, int n) {

@@ -51,27 +51,51 @@ inline int prereduce(float* part, int nrows, int ncols, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// statistics finalize
+// statistics finalize.  Partial sums are channel-major, part[2][C][nblk] (which, channel, producer workgroup), so
+// one channel's nblk values are contiguous: TPC threads (a wave, or the whole workgroup for long rows) read them
+// with 16-byte loads, accumulate in double and fold with shuffles - one launch whatever nblk is.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
+template <int TPC>
+__device__ __forceinline__ void channel_sums(const float* __restrict__ part, int nblk, int C, int c, int li, double& a,
+                                             double& b) {
+  const float* __restrict__ p0 = part + (long)c * nblk;
+  const float* __restrict__ p1 = part + ((long)C + c) * nblk;
+  a = 0.0; b = 0.0;
+  if ((nblk & 3) == 0) {
+    const float4* __restrict__ q0 = reinterpret_cast<const float4*>(p0);
+    const float4* __restrict__ q1 = reinterpret_cast<const float4*>(p1);
+    for (int i = li; i < (nblk >> 2); i += TPC) {
+      const float4 u = q0[i], v = q1[i];
+      a += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
+      b += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+  } else {
+    for (int i = li; i < nblk; i += TPC) { a += (double)p0[i]; b += (double)p1[i]; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+  if (TPC == 256) {                      // c is workgroup-uniform here: every thread reaches the barrier
+    __shared__ double r[2][4];
+    if ((threadIdx.x & 63) == 0) { r[0][threadIdx.x >> 6] = a; r[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    a = (r[0][0] + r[0][1]) + (r[0][2] + r[0][3]);
+    b = (r[1][0] + r[1][1]) + (r[1][2] + r[1][3]);
+  }
+}
+inline int finalize_tpc(int nblk) { return nblk > 256 ? 256 : 64; }
+
+template <int TPC>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long* num_batches, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* scale_out,
                                    float* shift_out) {
-  __shared__ double s1[32][33], s2[32][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 32 channels x 32 row groups
-  const int c = blockIdx.x * 32 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = rg; i < nblk; i += 32) {
-      a += (double)part[((long)i * 2 + 0) * C + c];
-      b += (double)part[((long)i * 2 + 1) * C + c];
-    }
-  s1[rg][cl] = a;
-  s2[rg][cl] = b;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    for (int k = 1; k < 32; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+  const int c = blockIdx.x * (256 / TPC) + threadIdx.x / TPC, li = threadIdx.x % TPC;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  if (c >= C) return;                    // wave-uniform (TPC >= 64); never taken when TPC == 256 (grid = C)
+  double a, b;
+  channel_sums<TPC>(part, nblk, C, c, li, a, b);
+  if (li == 0) {
     const double mean = a / count;
     double var = b / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -87,7 +111,6 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
 }
 
 __global__ void bn_eval_prepare_kernel(int C, const float* gamma, const float* beta, const float* rmean,
@@ -267,7 +290,7 @@ __device__ __forceinline__ int pcb_of(int C) {
   return p;
 }
 
-// partial[blk][2][C]: sum dz, sum dz*xhat.  grid = (channel groups, nblk)
+// partial[2][C][nblk] (channel-major): sum dz, sum dz*xhat.  grid = (channel groups, nblk)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, int ldg1, const T* gp, int ldgp, const float* scale, const float* shift,
                                           const T* x, int ldx, const float* mean, const float* invstd,
@@ -323,27 +346,19 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* g1, in
     Acc s = 0;
     for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
     const int c = blockIdx.x * PCB * 8 + cl;
-    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = (float)s;
+    if (c < C) part[((long)which * C + c) * gridDim.y + blockIdx.y] = (float)s;
   }
 }
 
-// sums partial[nblk][2][C] -> dgamma, dbeta (accumulate optional) and the two per-channel means
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
+// sums partial[2][C][nblk] -> dgamma, dbeta (accumulate optional) and the two per-channel means
+template <int TPC>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, double count, float* dgamma,
                                        float* dbeta, int accumulate, float* c1, float* c2, float* zero_out) {
-  __shared__ double s1[32][33], s2[32][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = rg; i < nblk; i += 32) {
-      a += (double)part[((long)i * 2 + 0) * C + c];
-      b += (double)part[((long)i * 2 + 1) * C + c];
-    }
-  s1[rg][cl] = a;
-  s2[rg][cl] = b;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    for (int k = 1; k < 32; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+  const int c = blockIdx.x * (256 / TPC) + threadIdx.x / TPC, li = threadIdx.x % TPC;
+  if (c >= C) return;
+  double a, b;
+  channel_sums<TPC>(part, nblk, C, c, li, a, b);
+  if (li == 0) {
     dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
     dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     c1[c] = (float)(a / count);
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_flat_kernel(const T* _
     Acc s = 0;
     for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
     const int c = blockIdx.x * PCB * 8 + cl;
-    if (c < C) part[((long)blockIdx.y * 2 + which) * C + c] = (float)s;
+    if (c < C) part[((long)which * C + c) * gridDim.y + blockIdx.y] = (float)s;
   }
 }
 
@@ -557,10 +572,14 @@ extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, c
                                void* stream) {
   if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift) return S2S_ERR_NULL;
   if (nblk <= 0 || C <= 0 || count <= 0) return S2S_ERR_SHAPE;
-  nblk = prereduce(const_cast<float*>(part), nblk, 2 * C, (hipStream_t)stream);   // part is scratch: reduced in place
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, C,
-                     (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
-                     invstd, scale, shift);
+  if (finalize_tpc(nblk) == 256)
+    hipLaunchKernelGGL(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
+                       invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
+                       invstd, scale, shift);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -630,7 +649,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
     return S2S_ERR_SHAPE;
   if ((long)B * ((H + 1) / 2) * ((W + 1) / 2) >= (1L << 31) - (1 << 20)) return S2S_ERR_SHAPE;   // 32-bit window index
   const int nb = red_blocks(B, H, W, C);
-  float* part = work;                       // [nb][2][C]
+  float* part = work;                       // [2][C][nb]
   float* part2 = work + (long)nb * 2 * C;   // [nb][C]
   float* c1 = part2 + (long)nb * 2 * C;     // [C]
   float* c2 = c1 + C;
@@ -653,8 +672,12 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
     hipLaunchKernelGGL(bn_relu_bwd_reduce_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,             \
                        scale, shift, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
   }                                                                                                                \
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part, prereduce(part, nb, 2 * C, s), \
-                     C, count, dgamma, dbeta, accumulate, c1, c2, dbias_zero);                                                       \
+  if (finalize_tpc(nb) == 256)                                                                                     \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<256>, dim3(C), dim3(256), 0, s, part, nb, C, count, dgamma, dbeta,   \
+                       accumulate, c1, c2, dbias_zero);                                                            \
+  else                                                                                                             \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, s, part, nb, C, count, dgamma,  \
+                       dbeta, accumulate, c1, c2, dbias_zero);                                                     \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
                        ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \

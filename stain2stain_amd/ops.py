@@ -143,7 +143,7 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     stat = None
     if want_stats:
         nb = _L().s2s_conv3x3_stat_blocks(dt, B, H, W, cout)
-        stat = torch.empty((nb, 2, cout), dtype=torch.float32, device=x0.device)
+        stat = torch.empty((2, cout, nb), dtype=torch.float32, device=x0.device)
     rc = _L().s2s_conv3x3_nhwc(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
                                _f32(scale), _f32(shift), int(relu), B, H, W, cout, _stream())
     _native.check(rc, "conv3x3")
@@ -183,7 +183,7 @@ def stem_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     y = torch.empty((B, H, W, cout), dtype=dtype, device=x_nchw.device)
     stat = None
     if want_stats:
-        stat = torch.empty((_L().s2s_stem_stat_blocks(B, H, W), 2, cout), dtype=torch.float32, device=y.device)
+        stat = torch.empty((2, cout, _L().s2s_stem_stat_blocks(B, H, W)), dtype=torch.float32, device=y.device)
     rc = _L().s2s_stem_conv3x3_fwd(_dt(y), _f32(x_nchw), _f32(w), _f32(bias), y.data_ptr(), cout, _f32(stat), B, H, W,
                                    cin, cout, _stream())
     _native.check(rc, "stem_conv3x3_fwd")
@@ -259,7 +259,7 @@ def head_loss_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 @_timed("bn_finalize")
 def bn_finalize(stat: torch.Tensor, count: int, gamma, beta, running_mean, running_var, num_batches,
                 momentum: float = 0.1, eps: float = 1e-5):
-    nblk, _, C = stat.shape
+    _, C, nblk = stat.shape                  # channel-major partial sums [2][C][producer workgroups]
     dev = stat.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
     rc = _L().s2s_bn_finalize(_f32(stat), nblk, C, count, _f32(gamma), _f32(beta), _f32(running_mean),

@@ -48,7 +48,7 @@ def test_conv_forward_dgrad_wgrad_random_shapes(case):
     y, stat = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, want_stats=True)
     assert relerr(nchw(y), ref.detach()) < 4e-3
     yb = nchw(y)                                                    # statistics are taken from the stored values
-    s = stat.sum(0).cpu()
+    s = stat.sum(-1).cpu()                 # [2][C][producer workgroups]
     assert float((s[0] - yb.sum((0, 2, 3))).abs().max()) < 1e-4 * float(yb.abs().sum((0, 2, 3)).max())
     assert relerr(s[1], (yb * yb).sum((0, 2, 3))) < 1e-4
     dx, _ = ops.conv3x3(nhwc(dy, BF), None, wd, None, cin)
@@ -82,7 +82,7 @@ def test_bn_relu_pool_backward_random_shapes(seed):
     loss.backward()
     zs = nhwc(z.detach(), BF)
     count = B * H * W
-    stat = torch.stack([z.detach().sum((0, 2, 3)), (z.detach() ** 2).sum((0, 2, 3))])[None].to(DEV)
+    stat = torch.stack([z.detach().sum((0, 2, 3)), (z.detach() ** 2).sum((0, 2, 3))])[..., None].to(DEV)
     st = ops.bn_finalize(stat.contiguous(), count, gamma.detach().to(DEV), beta.detach().to(DEV), None, None, None)
     act, pooled = ops.bn_relu_apply(zs, st[2], st[3], want_pool=pool)
     assert relerr(nchw(act), a) < 4e-3

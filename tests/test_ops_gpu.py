@@ -61,7 +61,7 @@ def test_conv3x3_forward_and_stats(case, dtype):
     y, stat = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, want_stats=True)
     torch.cuda.synchronize()
     assert relerr(nchw(y), ref) < tol_act(dtype)
-    s = stat.sum(0).cpu()
+    s = stat.sum(-1).cpu()                 # [2][C][producer workgroups]
     assert relerr(s[0], ref.sum((0, 2, 3))) < 2e-4 + (1e-3 if dtype == torch.bfloat16 else 0)
     assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 2e-4 + (1e-3 if dtype == torch.bfloat16 else 0)
 
@@ -131,7 +131,7 @@ def test_stem_and_head(dtype, cin, hc):
     ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1)   # bf16 mode stages image patch and weights in bf16
     y, stat = ops.stem_fwd(x.to(DEV), w.to(DEV), b.to(DEV), dtype)
     assert relerr(nchw(y), ref) < tol_act(dtype)
-    s = stat.sum(0).cpu()
+    s = stat.sum(-1).cpu()                 # [2][C][producer workgroups]
     assert relerr(s[0], ref.sum((0, 2, 3))) < 1e-4
     assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-4
     # stem weight/bias gradient
@@ -186,7 +186,7 @@ def test_bn_relu_pool_forward_backward(dtype, hw):
 
     zs = nhwc(z.detach(), dtype)
     n = B * H * W
-    stat = torch.stack([zs.float().sum((0, 1, 2)), (zs.float() ** 2).sum((0, 1, 2))])[None].contiguous()
+    stat = torch.stack([zs.float().sum((0, 1, 2)), (zs.float() ** 2).sum((0, 1, 2))])[..., None].contiguous()
     rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV); nb = torch.zeros((), dtype=torch.int64, device=DEV)
     st = ops.bn_finalize(stat, n, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv, nb)
     assert relerr(st[0].cpu(), mean) < 1e-5
