@@ -393,12 +393,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   }
 }
 
-// grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci].  A workgroup owns 64 consecutive (co,ci) pairs; its four
-// waves take every fourth split (reads stay coalesced along ci), the sums meet in LDS and leave as 64*9
-// contiguous floats of the OIHW gradient.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
+// grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci].  A workgroup owns 64 consecutive (co,ci) pairs; its ZG
+// waves take every ZG-th split (reads stay coalesced along ci), the sums meet in LDS and leave as 64*9
+// contiguous floats of the OIHW gradient.  ZG = 16 for the narrow layers: a 64 x 64 weight has only 64 such
+// workgroups but up to 400 splits to read, so the parallelism has to come from inside the workgroup.
+template <int ZG>
+__global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout,
                                     int Cin, int accumulate) {
-  __shared__ float tile[4][9][65];
+  __shared__ float tile[ZG][9][65];
   const long n = (long)Cout * Cin;
   const int il = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + il;  // (co, ci)
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
   if (i < n) {
-    for (int z = zg; z < S; z += 4)
+    for (int z = zg; z < S; z += ZG)
 #pragma unroll
       for (int t = 0; t < 9; ++t) s[t] += part[((long)z * 9 + t) * n + i];
   }
@@ -414,11 +416,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int t = 0; t < 9; ++t) tile[zg][t][il] = s[t];
   __syncthreads();
   const long base = (long)blockIdx.x * 64 * 9;
-  for (int k = threadIdx.x; k < 576; k += 256) {
+  for (int k = threadIdx.x; k < 576; k += 64 * ZG) {
     const long o = base + k;
     if (o < n * 9) {
       const int t = k % 9, j = k / 9;
-      const float v = tile[0][t][j] + tile[1][t][j] + tile[2][t][j] + tile[3][t][j];
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < ZG; g += 4) v += (tile[g][t][j] + tile[g + 1][t][j]) + (tile[g + 2][t][j] + tile[g + 3][t][j]);
       grad[o] = accumulate ? grad[o] + v : v;
     }
   }
@@ -520,8 +524,12 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   else return S2S_ERR_DTYPE;
   if (rc != S2S_OK) return rc;
   const long n = (long)Cout * (c0 + c1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, grad_oihw, a.S,
-                     Cout, c0 + c1, accumulate);
+  if (n <= 32768 && a.S >= 32)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, part, grad_oihw,
+                       a.S, Cout, c0 + c1, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, grad_oihw,
+                       a.S, Cout, c0 + c1, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -481,7 +481,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __restrict__ g1, int ldg1, const float* __restrict__ scale, const float* __restrict__ shift,
                                               const T* __restrict__ x, int ldx, const float* mean, const float* invstd,
                                               const float* gamma, const float* c1, const float* c2, T* __restrict__ dx,
-                                              int lddx, float* dxsum_part, long npix, int C) {
+                                              int lddx, float* dxsum_part, long npix, int C, int rev) {
   const int PCB = pcb_of(C), WL = 256 / PCB;
   const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
   const int c8 = (blockIdx.x * PCB + pc) * 8;
@@ -495,7 +495,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_flat_kernel(const T* __
       mu[k] = mean[c8 + k]; is[k] = invstd[c8 + k]; sc[k] = scale[c8 + k]; sh[k] = shift[c8 + k];
       ga[k] = gamma[c8 + k] * is[k]; k1[k] = c1[c8 + k]; k2[k] = c2[c8 + k];
     }
-    for (long p = (long)blockIdx.y * WL + wl; p < npix; p += (long)gridDim.y * WL) {
+    // rev: walk the tensor from its end - the reduction pass just read it front to back, so its tail is what the
+    // memory-side cache still holds
+    const long p0 = (long)blockIdx.y * WL + wl, pstep = (long)gridDim.y * WL;
+    const long nit = p0 < npix ? (npix - p0 + pstep - 1) / pstep : 0;
+    for (long it = 0; it < nit; ++it) {
+      const long p = p0 + (rev ? nit - 1 - it : it) * pstep;
       const f32x8 g = load8(g1 + p * ldg1 + c8);
       const f32x8 b = load8(x + p * ldx + c8);
       f32x8 o;
@@ -664,6 +669,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   float* const dbias_zero = (dbias_conv && !dbias_sum && !accumulate) ? dbias_conv : nullptr;
   if (dbias_conv && !dbias_sum) dbias_conv = nullptr;
   dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
+  static const int bn_rev = [] { const char* e = getenv("S2S_BN_REV"); return e ? atoi(e) : 1; }();
 #define S2S_BN_BWD(TT)                                                                                             \
   if (gp) {                                                                                                        \
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,   \
@@ -685,7 +691,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   } else {                                                                                                         \
     hipLaunchKernelGGL(bn_relu_bwd_apply_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,              \
                        scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,           \
-                       dbias_conv ? part2 : nullptr, (long)B * H * W, C);                                          \
+                       dbias_conv ? part2 : nullptr, (long)B * H * W, C, bn_rev);                                  \
   }
   if (dtype == S2S_BF16) { S2S_BN_BWD(bf16_t) }
   else if (dtype == S2S_F32) { S2S_BN_BWD(float) }
