@@ -1,0 +1,188 @@
+"""Parity at BASELINE.json's full sizes: the 13 conv layer shapes of the headline configuration (batch 16, 256x256,
+[64,128,256,512,1024]) through the tile configurations and split counts the bench actually runs, against torch's fp32
+CPU convolution on bf16-rounded operands (the oracle of the per-op tests, test_ops_gpu.py, at sizes it still
+finishes in seconds: forward and data gradient are compared on the first and last sample of the batch, which a
+convolution treats independently; the weight gradient, a sum over the batch, on all of it), and the whole network at
+batch 16 in its two arithmetic modes against each other.
+
+Tolerances: 4e-3 max-norm relative for bf16-stored outputs, 1e-4 for fp32 outputs (as in test_ops_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+B = 16
+
+# (H, c0, c1, cout): encoder convs, then the decoder's post-concat convs (skip | up-sampled)
+LAYERS = [(256, 64, 0, 64), (128, 64, 0, 128), (128, 128, 0, 128), (64, 128, 0, 256), (64, 256, 0, 256),
+          (32, 256, 0, 512), (32, 512, 0, 512), (16, 512, 0, 1024), (16, 1024, 0, 1024),
+          (32, 512, 1024, 512), (64, 256, 512, 256), (128, 128, 256, 128), (256, 64, 128, 64)]
+
+
+def _nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: "H%d_%d+%d_to_%d" % l)
+def test_headline_conv_layer_bf16(layer):
+    from stain2stain_amd import ops
+    H, c0, c1, cout = layer
+    cin = c0 + c1
+    g = torch.Generator(device=DEV).manual_seed(1984 + H + cin)
+    xs = (torch.rand(B, H, H, cin, device=DEV, generator=g) * 2 - 1).to(BF)          # NHWC, bf16-exact values
+    dys = (torch.rand(B, H, H, cout, device=DEV, generator=g) * 2 - 1).to(BF)
+    w = ((torch.rand(cout, cin, 3, 3, device=DEV, generator=g) * 2 - 1) * (3.0 / (9 * cin)) ** 0.5).to(BF).float()
+    b = torch.rand(cout, device=DEV, generator=g) - 0.5
+    x0, x1 = xs[..., :c0], (xs[..., c0:] if c1 else None)
+    wf, wd = ops.pack_conv3x3(w, BF)
+
+    y, stat = ops.conv3x3(x0, x1, wf, b, cout, want_stats=True)
+    dx, _ = ops.conv3x3(dys, None, wd, None, cin)
+    gw = torch.empty(cout, cin, 3, 3, device=DEV)
+    ops.conv3x3_wgrad(dys, x0, x1, gw)
+    torch.cuda.synchronize()
+
+    # statistics are taken from the stored (bf16) outputs, over the whole batch
+    yf = y.float()
+    s = stat.double().sum(-1)
+    assert relerr(s[0].float().cpu(), yf.double().sum((0, 1, 2)).float().cpu()) < 1e-4
+    assert relerr(s[1].float().cpu(), (yf.double() ** 2).sum((0, 1, 2)).float().cpu()) < 1e-4
+
+    sel = [0, B - 1]
+    xc = xs[sel].float().cpu().permute(0, 3, 1, 2).contiguous()
+    dyc = dys[sel].float().cpu().permute(0, 3, 1, 2).contiguous()
+    wc, bc = w.cpu(), b.cpu()
+    ref_y = F.conv2d(xc, wc, bc, padding=1)
+    assert relerr(_nchw(y[sel]), ref_y) < 4e-3
+    ref_dx = F.conv_transpose2d(dyc, wc, None, padding=1)
+    assert relerr(_nchw(dx[sel]), ref_dx) < 4e-3
+    del xc, dyc, ref_y, ref_dx
+
+    xa = xs.float().cpu().permute(0, 3, 1, 2).contiguous()
+    dya = dys.float().cpu().permute(0, 3, 1, 2).contiguous()
+    ref_gw = torch.nn.grad.conv2d_weight(xa, (cout, cin, 3, 3), dya, padding=1)
+    assert relerr(gw.cpu(), ref_gw) < 1e-4
+
+
+def test_headline_step_bf16_mode_agrees_with_parity_mode():
+    """One full optimisation step at the headline configuration (batch 16, 256x256, production widths) in the bf16
+    throughput mode and in the fp32 (split-bf16) mode that the golden fixtures pin to the reference: same weights,
+    same batch.  bf16 storage of 36 activation tensors bounds the agreement, not the kernels: the CPU oracle with
+    every conv operand and conv output rounded to bf16 (fp32 accumulation) moves the velocity by 7.3e-2 in L2 /
+    8.9e-2 max-norm at this size, this path by 7.3e-2 / 9.7e-2 (scripts/prod_parity.py, on the GPU box).  Bounds:
+    loss within 1 %, velocity 0.12 in L2 and 0.2 max-norm, every weight gradient pointing the same way."""
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    g = torch.Generator().manual_seed(1984)
+    x0 = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    x1 = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    t = torch.rand(B, generator=g).to(DEV)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(1984)
+        net = FlowUNet(precision=prec).to(DEV).train()
+        tr = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+        loss, v = tr.forward_backward(x0, x1, t)
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().float().clone() for k, p in net.named_parameters()}
+        out[prec] = (float(loss), v.detach().float().clone(), grads)
+        del tr, net
+    (l32, v32, g32), (l16, v16, g16) = out["fp32"], out["bf16"]
+    rel_l2 = float((v16 - v32).norm() / v32.norm())
+    rel_max = float((v16 - v32).abs().max() / v32.abs().max())
+    print(f"loss fp32 {l32:.6f} bf16 {l16:.6f}; velocity rel-L2 {rel_l2:.3e}, max-norm {rel_max:.3e}")
+    assert abs(l16 - l32) < 1e-2 * abs(l32)
+    assert rel_l2 < 0.12 and rel_max < 0.2
+    worst = 1.0
+    for k, a in g32.items():
+        if a.numel() < 64 or float(a.abs().max()) == 0.0:
+            continue                      # conv biases ahead of BatchNorm have an exactly-zero gradient
+        b_ = g16[k]
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        worst = min(worst, cos)
+        # yardstick: the oracle's autograd with bf16 storage of activations and gradients gives 0.83-0.87 in the
+        # encoder's first levels, 0.93 at ups.0 and 0.9995+ at ups.3 (profiles/r01_prod_parity_B16_256.txt)
+        assert cos > (0.999 if k.startswith(("flow_decoder.ups.3", "flow_decoder.outc")) else 0.75), (k, cos)
+    print(f"smallest gradient cosine {worst:.5f}")
+
+
+def test_headline_forward_fp32_mode_matches_the_oracle():
+    """The whole network at the headline size (batch 16, 256x256, production widths, training-mode BatchNorm) in the
+    fp32 parity mode against the CPU oracle's forward: north_star's 1e-3 relative tolerance on the velocity (measured
+    1.6e-5 max-norm, 1.4e-5 in L2), loss to 1e-5.  ~50 s of CPU time for the oracle."""
+    from oracle import unet_oracle as O
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    g = torch.Generator().manual_seed(1984)
+    x0 = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+    x1 = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+    t = torch.rand(B, generator=g)
+    torch.manual_seed(1984)
+    net = FlowUNet(precision="fp32").to(DEV).train()
+    P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    loss, v = tr.forward_backward(x0.to(DEV), x1.to(DEV), t.to(DEV))
+    v = v.detach().float().cpu()
+    del tr, net
+    import os
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))     # the GPU box reports more cores than its share
+    try:
+        with torch.no_grad():
+            xt, ut = O.cfm_sample(x0, x1, t)
+            v_ref = O.flow_forward(t, xt, P, True)
+            l_ref = float(O.cfm_loss(v_ref, ut))
+    finally:
+        torch.set_num_threads(threads)
+    assert relerr(v, v_ref) < 1e-3
+    assert float((v - v_ref).norm() / v_ref.norm()) < 1e-3
+    assert abs(float(loss) - l_ref) < 1e-5 * abs(l_ref)
+
+
+def test_headline_gradients_fp32_mode_against_the_oracle():
+    """Every parameter gradient of the production network on 256x256 tiles (batch 4, so that the oracle's autograd
+    finishes in seconds) in the fp32 parity mode against the oracle's fp32 autograd.
+
+    What 1e-3 can and cannot mean here: the network takes ~1e8 ReLU / max-pool decisions per step and some sit on a
+    knife edge, so two correct fp32 evaluations differ - the oracle's own fp32 gradients against its fp64 ones deviate
+    by up to 2.7e-2 (max-norm, per tensor) at this size, this path by up to 6.4e-2 against either
+    (profiles/r01_prod_grad_parity_B4_256.txt).  Decision-free parts are exact: the head and the last BatchNorm'd conv
+    agree to < 1e-4 (measured 2e-7 .. 3e-5), the rest of the last decoder level to 5e-3 (measured 1.2e-3); everything
+    else is bounded at 0.2.  The 1e-3 gradient criterion proper is checked on the screened golden fixtures
+    (test_e2e_gpu.py)."""
+    import os
+    from oracle import unet_oracle as O
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    nb = 4
+    g = torch.Generator().manual_seed(1984)
+    x0 = torch.rand(nb, 3, 256, 256, generator=g) * 2 - 1
+    x1 = torch.rand(nb, 3, 256, 256, generator=g) * 2 - 1
+    t = torch.rand(nb, generator=g)
+    torch.manual_seed(1984)
+    net = FlowUNet(precision="fp32").to(DEV).train()
+    P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    loss, v = tr.forward_backward(x0.to(DEV), x1.to(DEV), t.to(DEV))
+    got = {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters()}
+    del tr, net
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))     # the GPU box reports more cores than its share
+    try:
+        l_ref, v_ref, ref, _ = O.loss_and_grads(P, x0, x1, t)
+    finally:
+        torch.set_num_threads(threads)
+    assert relerr(v.float().cpu(), v_ref) < 1e-3 and abs(float(loss) - float(l_ref)) < 1e-5 * abs(float(l_ref))
+    gscale = max(float(r.abs().max()) for r in ref.values())
+    for k, r in ref.items():
+        if float(r.abs().max()) < 1e-3 * gscale:
+            continue                      # e.g. conv biases ahead of BatchNorm: exactly 0 here, rounding noise there
+        e = relerr(got[k], r)
+        if k.startswith(("flow_decoder.outc", "flow_decoder.ups.3.conv.double_conv.4")):
+            bound = 1e-4
+        elif k.startswith("flow_decoder.ups.3"):
+            bound = 5e-3
+        else:
+            bound = 0.2
+        assert e < bound, (k, e)
