@@ -154,7 +154,7 @@ def main() -> None:
             n_l = len(prof)
             t_l = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
             f_l = sum(w for _, w, _, _ in prof)
-            print(json.dumps({
+            _emit(json.dumps({
                 "metric": f"256x256 tiles/sec sampled ({args.euler_steps} Euler steps, eval-mode network)",
                 "value": round(B * world * args.steps / elapsed, 3), "unit": "tiles/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
@@ -168,7 +168,7 @@ def main() -> None:
                              "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                              "traffic": None, "launches_per_step": n_l // timed_steps,
-                             "launches_timed": n_l, "avg_launch_ms": round(t_l * 1e3 / n_l, 4)}}), flush=True)
+                             "launches_timed": n_l, "avg_launch_ms": round(t_l * 1e3 / n_l, 4)}}))
         if use_dist:
             dist.destroy_process_group()
         return
@@ -294,10 +294,29 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
 
+def _emit(line: str) -> None:
+    """The one JSON line goes to the process's real stdout (see _quiet_stdout)."""
+    os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
+def _quiet_stdout() -> None:
+    """Libraries write banners to C stdout (RCCL prints its version block there when the communicator is created):
+    point fd 1 at stderr for the life of the process and keep the original for the result line, so that stdout
+    carries exactly one line."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
 if __name__ == "__main__":
+    _quiet_stdout()
     main()
