@@ -111,7 +111,14 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            build()
+            import fcntl                   # one rank of a multi-process launch builds, the others wait for it
+            with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not os.path.exists(LIB_PATH):
+                        build()
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         try:
             _lib = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # loud failure: there is no CPU / eager path behind these ops
