@@ -186,3 +186,37 @@ def test_headline_gradients_fp32_mode_against_the_oracle():
         else:
             bound = 0.2
         assert e < bound, (k, e)
+
+
+def test_headline_sampling_path_matches_the_oracle_fp32():
+    """BASELINE.json configs[3] at production widths: the eval-mode network (BatchNorm folded into the conv epilogue,
+    running statistics after two training steps) on 256x256 tiles, one forward and a 4-step Euler integration,
+    against the oracle's eval-mode forward / Euler loop.  1e-3 on the velocity and on the sampled image."""
+    import os
+    from oracle import unet_oracle as O
+    from stain2stain_amd import CFMTrainer, FlowUNet, euler_generate
+    nb = 2
+    g = torch.Generator().manual_seed(1984)
+    x0 = torch.rand(nb, 3, 256, 256, generator=g) * 2 - 1
+    x1 = torch.rand(nb, 3, 256, 256, generator=g) * 2 - 1
+    t = torch.rand(nb, generator=g)
+    torch.manual_seed(1984)
+    net = FlowUNet(precision="fp32").to(DEV).train()
+    tr = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    for _ in range(2):
+        tr.step(x0.to(DEV), x1.to(DEV), t.to(DEV))
+    net.eval()
+    P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        v = net(t.to(DEV), x0.to(DEV)).float().cpu()
+        img = euler_generate(net, x0.to(DEV), 4).float().cpu()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    try:
+        with torch.no_grad():
+            v_ref = O.flow_forward(t, x0, P, False)
+            img_ref = O.euler_sample(P, x0, 4)
+    finally:
+        torch.set_num_threads(threads)
+    assert relerr(v, v_ref) < 1e-3
+    assert relerr(img, img_ref) < 1e-3
