@@ -27,10 +27,14 @@ def _nchw(y):
     return y.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: "H%d_%d+%d_to_%d" % l)
-def test_headline_conv_layer_bf16(layer):
+# + the two widest layers of BASELINE.json configs[4] (512x512 tiles, batch 8 per GPU)
+CASES = [(16,) + l for l in LAYERS] + [(8, 512, 64, 0, 64), (8, 512, 64, 128, 64)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_H%d_%d+%d_to_%d" % c)
+def test_headline_conv_layer_bf16(case):
     from stain2stain_amd import ops
-    H, c0, c1, cout = layer
+    B, H, c0, c1, cout = case
     cin = c0 + c1
     g = torch.Generator(device=DEV).manual_seed(1984 + H + cin)
     xs = (torch.rand(B, H, H, cin, device=DEV, generator=g) * 2 - 1).to(BF)          # NHWC, bf16-exact values
