@@ -224,3 +224,75 @@ def test_headline_sampling_path_matches_the_oracle_fp32():
         torch.set_num_threads(threads)
     assert relerr(v, v_ref) < 1e-3
     assert relerr(img, img_ref) < 1e-3
+
+
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("shape", [(256, 64), (128, 128), (32, 512)], ids=lambda s: "H%d_C%d" % s)
+def test_headline_batchnorm_relu_pool_bf16(shape):
+    """BatchNorm(train) -> ReLU -> {skip, MaxPool2d(2)} forward and backward at the headline layer sizes (batch 16,
+    bf16 storage) against the oracle's formulas evaluated with autograd in fp32 on the same device (67 M elements per
+    tensor at 256x256: the CPU would take minutes).  Element-wise outputs to 4e-3 max-norm; the input gradient in L2
+    (1e-3) because a ReLU decision within rounding of zero may legitimately differ between the two formulas for a
+    handful of the 67 M elements; dgamma / dbeta to 1e-3."""
+    from oracle import unet_oracle as O
+    from stain2stain_amd import ops
+    H, C = shape
+    g = torch.Generator(device=DEV).manual_seed(1984 + H)
+    zs = (torch.randn(16, H, H, C, device=DEV, generator=g) * 1.5 + 0.3).to(BF)              # NHWC conv output
+    gamma = torch.rand(C, device=DEV, generator=g) + 0.5
+    beta = torch.rand(C, device=DEV, generator=g) - 0.5
+    g1 = (torch.rand(16, H, H, C, device=DEV, generator=g) - 0.5).to(BF)
+    gp = (torch.rand(16, H // 2, H // 2, C, device=DEV, generator=g) - 0.5).to(BF)
+
+    z = zs.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)                      # NCHW fp32 reference
+    ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y, mean, var = O.batchnorm_train(z, ga, be)
+    y = y.clamp_min(0)
+    y = y + (y.detach().to(BF).float() - y.detach())              # the kernel stores y in bf16 and pools the stored value
+    p = O.maxpool2(y)
+    ((y * g1.float().permute(0, 3, 1, 2)).sum() + (p * gp.float().permute(0, 3, 1, 2)).sum()).backward()
+
+    n = 16 * H * H
+    zf = zs.float()
+    stat = torch.stack([zf.double().sum((0, 1, 2)), (zf.double() ** 2).sum((0, 1, 2))]).float()[..., None].contiguous()
+    st = ops.bn_finalize(stat, n, gamma, beta, None, None, None)
+    assert relerr(st[0], mean) < 1e-5 and relerr(st[1], torch.rsqrt(var + 1e-5)) < 1e-5
+    act, pool = ops.bn_relu_apply(zs, st[2], st[3], want_pool=True)
+    assert relerr(act.float().permute(0, 3, 1, 2), y) < 4e-3
+    assert torch.equal(pool, act.view(16, H // 2, 2, H // 2, 2, C).amax((2, 4)))             # pool of the stored values
+    dgam, dbet, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+    for gpool in (gp, None):
+        if gpool is None:                                          # flat variant (decoder layers: no pool gradient)
+            z.grad = None; ga.grad = None; be.grad = None
+            y2 = O.batchnorm_train(z, ga, be)[0].clamp_min(0)
+            (y2 * g1.float().permute(0, 3, 1, 2)).sum().backward()
+        dz = ops.bn_relu_bwd(g1, gpool, zs, st, gamma, dgam, dbet, dbias)
+        assert _rel_l2(dz.float().permute(0, 3, 1, 2), z.grad) < 3e-3          # bf16 storage of dz: 2^-9 per element
+        assert relerr(dgam, ga.grad) < 1e-3 and relerr(dbet, be.grad) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(128, 128), (16, 1024)], ids=lambda s: "Hin%d_C%d" % s)
+def test_headline_upsample_bf16(shape):
+    """Bilinear x2 (align_corners) forward into the concat buffer's channel slice and its backward at the headline
+    decoder sizes (batch 16), against torch's own bilinear up-sampling (the reference's nn.Upsample) in fp32 on the same
+    device."""
+    from stain2stain_amd import ops
+    Hin, C = shape
+    g = torch.Generator(device=DEV).manual_seed(1984 + Hin)
+    xs = (torch.rand(16, Hin, Hin, C, device=DEV, generator=g) * 2 - 1).to(BF)
+    bias = torch.rand(16, C, device=DEV, generator=g) - 0.5
+    gy = (torch.rand(16, 2 * Hin, 2 * Hin, C, device=DEV, generator=g) - 0.5).to(BF)
+    x = xs.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    up = F.interpolate(x + bias[:, :, None, None], scale_factor=2, mode="bilinear", align_corners=True)
+    (up * gy.float().permute(0, 3, 1, 2)).sum().backward()
+    cat = torch.zeros(16, 2 * Hin, 2 * Hin, C // 2 + C, device=DEV, dtype=BF)                # [skip | up]
+    ops.upsample2x_fwd(xs, cat[..., C // 2:], bias)
+    assert relerr(cat[..., C // 2:].float().permute(0, 3, 1, 2), up) < 4e-3
+    assert float(cat[..., :C // 2].abs().max()) == 0.0
+    gcat = torch.zeros_like(cat)
+    gcat[..., C // 2:] = gy
+    dx = ops.upsample2x_bwd(gcat[..., C // 2:], Hin, Hin)
+    assert relerr(dx.float().permute(0, 3, 1, 2), x.grad) < 4e-3
