@@ -207,6 +207,22 @@ int s2s_class_embed_add(const float* temb, const float* table, const long* y, fl
 int s2s_class_embed_bwd(const float* dout, const long* y, float* dtable, int accumulate, int B, int dim,
                         int num_classes, void* stream);
 
+/* ---- InstanceNorm2d + LeakyReLU, fused (instnorm.hip) ----------------------------------------------
+ * Row a13 of SURVEY.md section 8 (pix2pix generator / PatchGAN discriminator named by BASELINE.json's north_star).
+ * The reference repository has no such model, so these replace no reference line: the semantics are
+ * torch's nn.InstanceNorm2d(C, eps, affine = gamma/beta given or both NULL, no running statistics) followed by
+ * nn.LeakyReLU(slope) (slope 0 = ReLU), NHWC with a pixel stride, C % 8 == 0.
+ * work: float[2*B*C*s2s_instnorm_blocks()] for the forward, that + 2*B*C for the backward.
+ * stats: float[4][B][C] = mean, 1/std, scale, shift; written by the forward, read by the backward.
+ * backward: dx = d/dx of sum(g * y); dgamma/dbeta (both or neither) receive or accumulate the affine gradients. */
+int s2s_instnorm_blocks(int B, int H, int W, int C);
+int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                           float* work, float* stats, int B, int H, int W, int C, float eps, float slope,
+                           void* stream);
+int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const float* stats, void* dx,
+                           int lddx, float* dgamma, float* dbeta, int accumulate, float* work, int B, int H, int W,
+                           int C, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

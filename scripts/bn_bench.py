@@ -50,3 +50,13 @@ for Hin, C in [(16, 1024), (32, 512), (64, 256), (128, 128)]:
     t_b = timeit(lambda: ops.upsample2x_bwd(dy, Hin, Hin))
     gb = B * Hin * Hin * C * 2 * 5 / 1e9
     print(f"Hin{Hin:4d} C{C:5d} | fwd {t_f:6.1f} us ({gb/t_f*1e3:5.2f} TB/s) | fwd+bias {t_fb:6.1f} us | bwd {t_b:6.1f} us ({gb/t_b*1e3:5.2f} TB/s)", flush=True)
+
+print("InstanceNorm + LeakyReLU (pix2pix generator levels, batch 16)")
+for H, C in [(128, 64), (64, 128), (32, 256), (16, 512)]:
+    x = torch.randn(B, H, H, C, device=dev).to(dt)
+    g = torch.randn(B, H, H, C, device=dev).to(dt)
+    y, st = ops.instnorm_lrelu_fwd(x, None, None)
+    t_f = timeit(lambda: ops.instnorm_lrelu_fwd(x, None, None))
+    t_b = timeit(lambda: ops.instnorm_lrelu_bwd(g, x, st))
+    gb = B * H * H * C * 2 / 1e9
+    print(f"H{H:4d} C{C:5d} | fwd {t_f:6.1f} us ({3*gb/t_f*1e3:5.2f} TB/s) | bwd {t_b:6.1f} us ({5*gb/t_b*1e3:5.2f} TB/s)", flush=True)

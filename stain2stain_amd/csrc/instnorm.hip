@@ -1,0 +1,263 @@
+// Fused InstanceNorm2d + LeakyReLU (forward and backward), NHWC, HBM-bound.
+//
+// Row a13 of the scope table: the norm + activation pair of the pix2pix generator /
+// PatchGAN discriminator that BASELINE.json's north_star names.  The reference repository holds no such model
+// (SURVEY.md F1), so there is no reference file to cite: the semantics are torch's
+// nn.InstanceNorm2d(C, eps=1e-5, affine=False|True, track_running_stats=False) followed by
+// nn.LeakyReLU(negative_slope) (slope 0 = the decoder's ReLU), and the tests compare against exactly those.
+//
+//   forward : per-(sample, channel) partial (sum, sum^2) over pixel blocks -> finalize (mean, 1/std, folded
+//             scale/shift) -> one pass y = lrelu(x*scale + shift).  Three tensor passes (x twice, y once).
+//   backward: dz = g * lrelu'(z) recomputed from x; partial (sum dz, sum dz*xhat) -> finalize (the two
+//             per-(sample, channel) means; dgamma/dbeta = sums over the batch when affine) ->
+//             dx = gamma*invstd*(dz - c1 - xhat*c2).  Five tensor passes, like the BatchNorm backward of
+//             norm_act.hip, with the statistics indexed per sample.
+//
+// Layout and thread mapping follow norm_act.hip: [B][H][W][C] views with an explicit pixel stride, every
+// thread moves 16-B (bf16) / 32-B (fp32) pieces (8 channels of one pixel); partial sums are channel-major
+// ([2][B*C][blocks]) so that the finalize reads each (sample, channel) row contiguously.
+#include "common.h"
+
+namespace {
+
+__host__ __device__ inline int in_pcb(int C) {       // channel pieces (of 8) per workgroup
+  int p = 1;
+  while (p < 32 && p * 8 < C) p <<= 1;
+  return p;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void in_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ g, int ldg,
+                                                        const float* __restrict__ stats, float* __restrict__ part, int B,
+                                                        int HW, int C, float slope) {
+  const int PCB = in_pcb(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int n = blockIdx.z, c8 = (blockIdx.x * PCB + pc) * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (c8 < C) {
+    float mu[8], is[8], sc[8], sh[8];
+    if (BWD) {
+      const long BC = (long)B * C, o = (long)n * C + c8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mu[k] = stats[o + k]; is[k] = stats[BC + o + k]; sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
+    }
+    const T* const xb = x + (long)n * HW * ldx + c8;
+    const T* const gb = BWD ? g + (long)n * HW * ldg + c8 : nullptr;
+    for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
+      const f32x8 v = load8(xb + (long)p * ldx);
+      if (BWD) {
+        const f32x8 gv = load8(gb + (long)p * ldg);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] : slope * gv.v[k];
+          s1[k] += dz;
+          s2[k] = fmaf(dz, (v.v[k] - mu[k]) * is[k], s2[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] += v.v[k]; s2[k] = fmaf(v.v[k], v.v[k], s2[k]); }
+      }
+    }
+  }
+  __shared__ float red[2][2304];
+  const int rowlen = PCB * 8 + 1;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][wl * rowlen + pc * 8 + k] = s1[k]; red[1][wl * rowlen + pc * 8 + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * PCB * 8; i += 256) {
+    const int which = i / (PCB * 8), cl = i - which * (PCB * 8);
+    float s = 0.f;
+    for (int r = 0; r < WL; ++r) s += red[which][r * rowlen + cl];
+    const int c = blockIdx.x * PCB * 8 + cl;
+    if (c < C) part[(((long)which * B + n) * C + c) * gridDim.y + blockIdx.y] = s;
+  }
+}
+
+// one wave per (sample, channel): row of nblk partials -> the two sums in double
+__device__ __forceinline__ void in_row_sums(const float* __restrict__ part, long BC, long i, int nblk, int lane, double& a,
+                                            double& b) {
+  a = 0.0; b = 0.0;
+  for (int k = lane; k < nblk; k += 64) { a += (double)part[i * nblk + k]; b += (double)part[(BC + i) * nblk + k]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+}
+
+// stats[4][B][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale)
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ part, int nblk, int B, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float* __restrict__ stats) {
+  const long BC = (long)B * C, i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= BC) return;
+  double a, b;
+  in_row_sums(part, BC, i, nblk, threadIdx.x & 63, a, b);
+  if ((threadIdx.x & 63) == 0) {
+    const int c = (int)(i % C);
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+    stats[i] = (float)mean;
+    stats[BC + i] = invstd;
+    stats[2 * BC + i] = sc;
+    stats[3 * BC + i] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+  }
+}
+
+// cs[2][B][C] = per-(sample, channel) sums of dz and dz*xhat
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int B, int C,
+                                                              float* __restrict__ cs) {
+  const long BC = (long)B * C, i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= BC) return;
+  double a, b;
+  in_row_sums(part, BC, i, nblk, threadIdx.x & 63, a, b);
+  if ((threadIdx.x & 63) == 0) { cs[i] = (float)a; cs[BC + i] = (float)b; }
+}
+
+// dbeta[c] (+)= sum_n cs[0][n][c], dgamma[c] (+)= sum_n cs[1][n][c]
+__global__ void in_affine_grad_kernel(const float* __restrict__ cs, int B, int C, float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < B; ++n) { a += (double)cs[(long)n * C + c]; b += (double)cs[((long)B + n) * C + c]; }
+  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_lrelu_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                                             T* __restrict__ y, int ldy, int B, int HW, int C, float slope) {
+  const int PCB = in_pcb(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int n = blockIdx.z, c8 = (blockIdx.x * PCB + pc) * 8;
+  if (c8 >= C) return;
+  const long BC = (long)B * C, o = (long)n * C + c8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
+  const T* const xb = x + (long)n * HW * ldx + c8;
+  T* const yb = y + (long)n * HW * ldy + c8;
+  for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
+    const f32x8 v = load8(xb + (long)p * ldx);
+    f32x8 o8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float z = fmaf(v.v[k], sc[k], sh[k]);
+      o8.v[k] = z > 0.f ? z : slope * z;
+    }
+    store8(yb + (long)p * ldy, o8);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx,
+                                                                 const float* __restrict__ stats, const float* __restrict__ cs,
+                                                                 T* __restrict__ dx, int lddx, int B, int HW, int C,
+                                                                 float slope) {
+  const int PCB = in_pcb(C), WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int n = blockIdx.z, c8 = (blockIdx.x * PCB + pc) * 8;
+  if (c8 >= C) return;
+  const long BC = (long)B * C, o = (long)n * C + c8;
+  const float inv_hw = 1.f / (float)HW;
+  float mu[8], is[8], sc[8], sh[8], k1[8], k2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = stats[o + k]; is[k] = stats[BC + o + k]; sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k];
+    k1[k] = cs[o + k] * inv_hw; k2[k] = cs[BC + o + k] * inv_hw;
+  }
+  const T* const xb = x + (long)n * HW * ldx + c8;
+  const T* const gb = g + (long)n * HW * ldg + c8;
+  T* const db = dx + (long)n * HW * lddx + c8;
+  for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
+    const f32x8 v = load8(xb + (long)p * ldx);
+    const f32x8 gv = load8(gb + (long)p * ldg);
+    f32x8 o8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] : slope * gv.v[k];
+      o8.v[k] = sc[k] * (dz - k1[k] - ((v.v[k] - mu[k]) * is[k]) * k2[k]);      // sc = gamma * invstd
+    }
+    store8(db + (long)p * lddx, o8);
+  }
+}
+
+inline int in_blocks(int B, int H, int W, int C) {
+  const int pcb = in_pcb(C), wl = 256 / pcb, groups = cdiv(C / 8, pcb);
+  const long hw = (long)H * W;
+  long nb = cdiv(4096, groups * B);                 // ~16 workgroups per CU over the whole launch
+  const long most = (hw + wl - 1) / wl;
+  if (nb > most) nb = most;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+inline bool in_args_ok(int B, int H, int W, int C, int ld0, int ld1) {
+  return B > 0 && H > 0 && W > 0 && C > 0 && (C % 8) == 0 && (ld0 % 8) == 0 && (ld1 % 8) == 0 && B <= 65535 &&
+         (long)H * W < (1L << 31) && (long)B * C < (1L << 31);
+}
+
+}  // namespace
+
+extern "C" int s2s_instnorm_blocks(int B, int H, int W, int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return S2S_ERR_SHAPE;
+  return in_blocks(B, H, W, C);
+}
+
+extern "C" int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y,
+                                      int ldy, float* work, float* stats, int B, int H, int W, int C, float eps,
+                                      float slope, void* stream) {
+  if (!x || !y || !work || !stats) return S2S_ERR_NULL;
+  if ((gamma == nullptr) != (beta == nullptr)) return S2S_ERR_NULL;
+  if (!in_args_ok(B, H, W, C, ldx, ldy)) return S2S_ERR_SHAPE;
+  if ((long)H * W <= 1) return S2S_ERR_SHAPE;      // torch raises for a single spatial element in training mode
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = in_blocks(B, H, W, C), HW = H * W;
+  const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, B);
+  const unsigned fin = (unsigned)(((long)B * C + 3) / 4);
+#define S2S_IN_FWD(TT)                                                                                              \
+  hipLaunchKernelGGL((in_reduce_kernel<TT, false>), grid, dim3(256), 0, s, (const TT*)x, ldx, (const TT*)nullptr, 0, \
+                     (const float*)nullptr, work, B, HW, C, 0.f);                                                    \
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(fin), dim3(256), 0, s, work, nb, B, C, (double)HW, gamma, beta, eps,   \
+                     stats);                                                                                         \
+  hipLaunchKernelGGL(in_lrelu_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)x, ldx, stats, (TT*)y, ldy, B, HW, \
+                     C, slope)
+  if (dtype == S2S_BF16) { S2S_IN_FWD(bf16_t); }
+  else if (dtype == S2S_F32) { S2S_IN_FWD(float); }
+  else return S2S_ERR_DTYPE;
+#undef S2S_IN_FWD
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const float* stats,
+                                      void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, float* work,
+                                      int B, int H, int W, int C, float slope, void* stream) {
+  if (!g || !x || !stats || !dx || !work) return S2S_ERR_NULL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return S2S_ERR_NULL;
+  if (!in_args_ok(B, H, W, C, ldx, ldg) || (lddx % 8)) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = in_blocks(B, H, W, C), HW = H * W;
+  float* const part = work;                                   // [2][B*C][nb]
+  float* const cs = work + (size_t)2 * B * C * nb;            // [2][B][C]
+  const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, B);
+  const unsigned fin = (unsigned)(((long)B * C + 3) / 4);
+#define S2S_IN_BWD(TT)                                                                                              \
+  hipLaunchKernelGGL((in_reduce_kernel<TT, true>), grid, dim3(256), 0, s, (const TT*)x, ldx, (const TT*)g, ldg,      \
+                     stats, part, B, HW, C, slope);                                                                  \
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(fin), dim3(256), 0, s, part, nb, B, C, cs);                        \
+  if (dgamma)                                                                                                        \
+    hipLaunchKernelGGL(in_affine_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, cs, B, C, dgamma, dbeta,          \
+                       accumulate);                                                                                  \
+  hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g, ldg, (const TT*)x, ldx,     \
+                     stats, cs, (TT*)dx, lddx, B, HW, C, slope)
+  if (dtype == S2S_BF16) { S2S_IN_BWD(bf16_t); }
+  else if (dtype == S2S_F32) { S2S_IN_BWD(float); }
+  else return S2S_ERR_DTYPE;
+#undef S2S_IN_BWD
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

@@ -585,3 +585,43 @@ def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate
     _native.check(_L().s2s_nhwc_to_nchw(_dt(x), px, ldx, _f32(out), int(accumulate), B, C, H, W, _stream()),
                   "nhwc_to_nchw")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm2d + LeakyReLU (row a13: pix2pix generator / PatchGAN discriminator building block)
+# ------------------------------------------------------------------------------------------------
+@_timed("instnorm_lrelu_fwd")
+def instnorm_lrelu_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+                       eps: float = 1e-5, slope: float = 0.2, out: Optional[torch.Tensor] = None):
+    """y = leaky_relu(instance_norm(x), slope) on an NHWC view; returns (y, stats[4][B][C])."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device) if out is None else out
+    py, ldy = _nhwc(y)
+    nb = _L().s2s_instnorm_blocks(B, H, W, C)
+    _native.check(min(nb, 0), "instnorm_blocks")
+    work = torch.empty(2 * B * C * nb, dtype=torch.float32, device=x.device)
+    stats = torch.empty((4, B, C), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_instnorm_lrelu_fwd(_dt(x), px, ldx, _f32(gamma), _f32(beta), py, ldy, _f32(work), _f32(stats), B, H, W,
+                                     C, eps, slope, _stream())
+    _native.check(rc, "instnorm_lrelu_fwd")
+    return y, stats
+
+
+@_timed("instnorm_lrelu_bwd")
+def instnorm_lrelu_bwd(g: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, slope: float = 0.2,
+                       dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                       accumulate: bool = False) -> torch.Tensor:
+    B, H, W, C = x.shape
+    if g.shape != x.shape or g.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: instnorm_lrelu_bwd operand mismatch")
+    pg, ldg = _nhwc(g)
+    px, ldx = _nhwc(x)
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    nb = _L().s2s_instnorm_blocks(B, H, W, C)
+    _native.check(min(nb, 0), "instnorm_blocks")
+    work = torch.empty(2 * B * C * nb + 2 * B * C, dtype=torch.float32, device=x.device)
+    rc = _L().s2s_instnorm_lrelu_bwd(_dt(x), pg, ldg, px, ldx, _f32(stats), dx.data_ptr(), C, _f32(dgamma), _f32(dbeta),
+                                     int(accumulate), _f32(work), B, H, W, C, slope, _stream())
+    _native.check(rc, "instnorm_lrelu_bwd")
+    return dx
