@@ -492,9 +492,9 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (wgrad_kh_split(dtype, Cin, Cout) ? 3 : 1);
   static const int target = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
   // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
-  // slab, so the few-channel layers (mn = 1..2) stop at 320 splits
+  // slab, so the two-tile layers stop at 320 splits (a single-tile layer takes all 512)
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
-  const int cap = cap_env ? cap_env : (mn == 1 ? 400 : 320);   // measured at 64->64, 256x256, batch 16: 320 -> 136 us, 400 -> 129 us
+  const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
   int s = target / mn;
   if (s > cap) s = cap;
   if (s > nt) s = nt;
