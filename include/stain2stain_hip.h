@@ -223,6 +223,17 @@ int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int
                            int lddx, float* dgamma, float* dbeta, int accumulate, float* work, int B, int H, int W,
                            int C, float slope, void* stream);
 
+/* ---- 2x2-tap convolution on the MFMA loop (conv3x3_mfma.hip) -----------------------------------------
+ * Row a13 again (no reference line to replace): nn.Conv2d(k=4, stride=2, padding=1) of a pix2pix
+ * encoder / PatchGAN layer is a 2x2 "valid" convolution over the space-to-depth image of the zero-padded input
+ * (4*Cin channels, no wasted MACs) - pad = 0, input (H+1) x (W+1) - and its data gradient, which is also
+ * nn.ConvTranspose2d(k=4, stride=2, padding=1), is the same loop with flipped taps - pad = 1, input (H-1) x (W-1).
+ * H, W: OUTPUT size.  w_packed: bf16 [ceil(cin/32)][tap a*2+b][Cout][32].  bf16 only so far.
+ * stat_part (optional): float[2][Cout][s2s_conv2x2_stat_blocks()] as for the 3x3 kernel. */
+int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout);
+int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, void* y,
+                     int ldy, float* stat_part, int B, int H, int W, int Cout, int pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -904,6 +904,181 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
+// =========================================================================================================
+// 2x2-tap variant of the loop above.  A 4x4 stride-2 pad-1 convolution is a 2x2
+// "valid" convolution over the space-to-depth image of the padded input (K = 4 taps x 4*Cin, no wasted MACs), and its
+// data gradient / the 4x4 stride-2 transposed convolution is the same loop with the taps flipped and the origin
+// shifted by one: PAD = 0 reads input (i + a, j + b) and has Hin = H + 1, PAD = 1 reads (i + a - 1, j + b - 1) and has
+// Hin = H - 1 (a.H, a.W are the OUTPUT size, as everywhere).  Same halo image, weight ring, swizzle, operand order and
+// epilogue as conv3x3_dma16_kernel; weights packed [chunk][tap a*2+b][Cout][32].  One source tensor.
+// =========================================================================================================
+template <int TH, int TW, int BN, int WM, int WN, int NS, int PAD>
+__global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
+  using T = bf16_t;
+  constexpr int TAPS = 4;
+  constexpr int HP = TW + 4, HH_ = TH + 1, ROWS = HH_ * HP;
+  constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + 3) / 4;
+  constexpr int A_BYTES = HG * 4 * 1024;
+  constexpr int BG = BN / 64;
+  constexpr int B_BYTES = BN * 64;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int RB = TW / 16;
+  static_assert(WM * WN == 4 && BN % 64 == 0 && NS == 4 && TW % 16 == 0 && WTM % TW == 0, "configuration");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;
+  char* const ldsB = smem + 2 * A_BYTES;
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const char* __restrict__ wp = static_cast<const char*>(a.w);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int cl = lane & 15, kp = lane >> 4;
+  int bt = blockIdx.x;
+  const int tx = bt % a.tilesX; bt /= a.tilesX;
+  const int ty = bt % a.tilesY;
+  const int img = bt / a.tilesY;
+  const int y0 = ty * TH, x0p = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  const int Hi = PAD ? a.H - 1 : a.H + 1, Wi = PAD ? a.W - 1 : a.W + 1;
+
+  const int drow = lane >> 2, dslot = lane & 3;
+  int apix[HG], apc[HG];
+#pragma unroll
+  for (int j = 0; j < HG; ++j) {
+    const int row = (wave + 4 * j) * 16 + drow;
+    const int hy = row / HP, hx = row - hy * HP;
+    const int gy = y0 - PAD + hy, gx = x0p - PAD + hx;
+    apix[j] = (row < ROWS && hx < TW + 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? (img * Hi + gy) * Wi + gx : -1;
+    apc[j] = (dslot ^ ((-(hx >> 2)) & 3)) * 8;
+  }
+  const char* wptr[BG];
+  int wstep[BG];
+#pragma unroll
+  for (int j = 0; j < BG; ++j) {
+    const int n = (wave + 4 * j) * 16 + drow;
+    const bool ok = n0 + n < a.Cout;
+    wptr[j] = ok ? wp + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
+    wstep[j] = ok ? a.Cout * 64 : 0;
+  }
+  auto dma_halo = [&](int c) {
+    char* dst = ldsA + (c & 1) * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      const int ch = c * 32 + apc[j];
+      const void* g = g_zero_page;
+      if (apix[j] >= 0 && ch < a.c0) g = x0 + (long)apix[j] * a.ld0 + ch;
+      dma16(g, dst + j * 4096);
+    }
+  };
+  auto dma_w = [&](int slot) {
+    char* dst = ldsB + slot * B_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      dma16(wptr[j], dst + j * 4096);
+      wptr[j] += wstep[j];
+    }
+  };
+  int aofs[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw) {
+      const int px = rb * 16 + cl + kw;
+      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ ((-(px >> 2)) & 3)) << 4);
+    }
+  const int nrow = wn * WTN + cl;
+  const int bofs = nrow * 64 + ((kp ^ ((-(nrow >> 2)) & 3)) << 4);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
+
+  auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int kh = tap / 2, kw = tap % 2;
+    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+  };
+  dma_halo(0);
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // nchunk * 4 >= 3 slabs always exist
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int c = 0;
+  for (; c + 1 < a.nchunk; ++c) {
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * TAPS;
+    static_for<TAPS>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap == 0) dma_halo(c + 1);
+      dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  float biasr[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * WTN + ni * 16 + 4 * kp + j;
+      biasr[ni][j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+    }
+  {
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * TAPS;
+    static_for<TAPS>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap + NS - 1 < TAPS) dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + NS - 1 < TAPS) wait_vm<(NS - 2) * BG>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int PAD>
+int launch_conv2x2(Conv3x3Args& a, hipStream_t s) {
+  constexpr int NS = 4;
+  constexpr int ROWS = (TH + 1) * (TW + 4);
+  constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
+  constexpr int lds = 2 * HG * 4 * 1024 + NS * BN * 64;      // the epilogue stages inside this (static_assert there)
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  auto kern = conv2x2_dma16_kernel<TH, TW, BN, WM, WN, NS, PAD>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 int launch_dma(Conv3x3Args& a, hipStream_t s) {
   constexpr int ROWS = (TH + 2) * (TW + 4);
@@ -1229,4 +1404,38 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   return dispatch(dtype, a, s);
+}
+
+// ---- 2x2-tap convolution (row a13: 4x4 stride-2 conv / conv-transpose on the space-to-depth image) ----------------
+// Output H x W; pad 0: input (H+1) x (W+1), y[i][j] = sum_{a,b} W[a][b] x[i+a][j+b]; pad 1: input (H-1) x (W-1),
+// y[i][j] = sum_{a,b} W[a][b] x[i+a-1][j+b-1] (zero outside).  w_packed: bf16 [ceil(Cin/32)][4][Cout][32].
+extern "C" int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
+  return B * cdiv(H, 8) * cdiv(W, W > 16 ? 32 : 16);
+}
+
+extern "C" int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
+                                void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
+                                void* stream) {
+  if (!x || !w_packed || !y) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;                 // throughput mode only so far
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8)) return S2S_ERR_SHAPE;
+  if (pad != 0 && pad != 1) return S2S_ERR_SHAPE;
+  if (pad == 1 && (H < 2 || W < 2)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;     // 32-bit pixel index in the halo loader
+  Conv3x3Args a;
+  a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
+  a.ep_scale = a.ep_shift = nullptr;
+  a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
+  a.tilesX = a.tilesY = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wide = W > 16, big = Cout > 64;
+  if (pad == 0) {
+    if (wide) return big ? launch_conv2x2<8, 32, 128, 2, 2, 0>(a, s) : launch_conv2x2<8, 32, 64, 4, 1, 0>(a, s);
+    return big ? launch_conv2x2<8, 16, 128, 2, 2, 0>(a, s) : launch_conv2x2<8, 16, 64, 2, 2, 0>(a, s);
+  }
+  if (wide) return big ? launch_conv2x2<8, 32, 128, 2, 2, 1>(a, s) : launch_conv2x2<8, 32, 64, 4, 1, 1>(a, s);
+  return big ? launch_conv2x2<8, 16, 128, 2, 2, 1>(a, s) : launch_conv2x2<8, 16, 64, 2, 2, 1>(a, s);
 }

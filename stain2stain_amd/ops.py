@@ -625,3 +625,24 @@ def instnorm_lrelu_bwd(g: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, sl
                                      int(accumulate), _f32(work), B, H, W, C, slope, _stream())
     _native.check(rc, "instnorm_lrelu_bwd")
     return dx
+
+
+@_timed("conv2x2_mfma", lambda x, w_packed, bias, cout, pad, **kw: 2.0 * x.shape[0] * (x.shape[1] + (1 if pad else -1))
+        * (x.shape[2] + (1 if pad else -1)) * cout * 4 * x.shape[3])
+def conv2x2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pad: int, *,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """2x2-tap convolution on the MFMA loop (row a13): pad 0 -> output (Hi-1) x (Wi-1) ("valid"), pad 1 -> output
+    (Hi+1) x (Wi+1) (the data-gradient / transposed form).  x: NHWC bf16 view; w_packed: bf16 [cin/32][4][cout][32]."""
+    B, Hi, Wi, cin = x.shape
+    H, W = (Hi + 1, Wi + 1) if pad else (Hi - 1, Wi - 1)
+    if x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16:
+        raise RuntimeError("stain2stain_amd: conv2x2 runs in bf16 only")
+    if w_packed.numel() != ((cin + 31) // 32) * 4 * cout * 32:
+        raise RuntimeError("stain2stain_amd: conv2x2 packed weight has the wrong size")
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device) if out is None else out
+    py, ldy = _nhwc(y)
+    rc = _L().s2s_conv2x2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), py, ldy, 0, B, H, W, cout, int(pad),
+                               _stream())
+    _native.check(rc, "conv2x2")
+    return y

@@ -71,3 +71,62 @@ class InstanceNormLeakyReLU(nn.Module):
             raise ValueError("Expected more than 1 spatial element when training")          # torch's own message
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
         return _InstNormLReLU.apply(x, self.weight, self.bias, self.eps, self.negative_slope)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 4x4 stride-2 convolution / transposed convolution on the 2x2-tap MFMA kernel (forward and data gradient; the weight
+# gradient kernel is not built yet).  The layout changes below (space-to-depth of the padded image and its inverse, the
+# weight packing) are plain torch copies for now: they are bandwidth-bound re-orderings that belong in the epilogue of
+# the producing norm kernel.
+# ------------------------------------------------------------------------------------------------------------------
+def space_to_depth_pad1(x: torch.Tensor) -> torch.Tensor:
+    """NHWC [B,H,W,C] (H, W even) -> [B,H/2+1,W/2+1,4C]: out[p,q,(r*2+s)*C+c] = xpad[2p+r, 2q+s, c], xpad = x with a
+    one-pixel zero border."""
+    B, H, W, C = x.shape
+    if H % 2 or W % 2:
+        raise ValueError("space_to_depth_pad1: even spatial size expected")
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    xp = xp.view(B, H // 2 + 1, 2, W // 2 + 1, 2, C).permute(0, 1, 3, 2, 4, 5)
+    return xp.reshape(B, H // 2 + 1, W // 2 + 1, 4 * C)
+
+
+def depth_to_space_unpad1(xs: torch.Tensor) -> torch.Tensor:
+    """Inverse of space_to_depth_pad1 (drops the border)."""
+    B, Hs, Ws, C4 = xs.shape
+    C = C4 // 4
+    x = xs.view(B, Hs, Ws, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * Hs, 2 * Ws, C)
+    return x[:, 1:-1, 1:-1, :].contiguous()
+
+
+def _chunks32(m: torch.Tensor) -> torch.Tensor:
+    """[rows, 4 taps, K] fp32 -> bf16 [ceil(K/32)][4][rows][32] (the slab order of the kernel's weight ring)."""
+    rows, taps, K = m.shape
+    kp = (K + 31) // 32 * 32
+    if kp != K:
+        m = torch.nn.functional.pad(m, (0, kp - K))
+    return m.view(rows, taps, kp // 32, 32).permute(2, 1, 0, 3).contiguous().to(torch.bfloat16)
+
+
+def pack_conv4x4_s2(w: torch.Tensor):
+    """nn.Conv2d(k=4, s=2, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv2x2_nhwc.
+    Forward: tap (a,b), k = (r*2+s)*Cin + c  <-  w[o, c, 2a+r, 2b+s].  Data gradient: the same with the taps flipped and
+    the roles of k and o exchanged."""
+    Cout, Cin = w.shape[:2]
+    w6 = w.detach().float().view(Cout, Cin, 2, 2, 2, 2)                 # o, c, a, r, b, s
+    w2 = w6.permute(0, 2, 4, 3, 5, 1).reshape(Cout, 4, 4 * Cin)         # o, (a,b), (r,s,c)
+    fwd = _chunks32(w2)
+    wd = w2.flip(1).permute(2, 1, 0).contiguous()                        # k, (1-a,1-b), o
+    return fwd, _chunks32(wd)
+
+
+def conv4x4_s2(x: torch.Tensor, w_fwd: torch.Tensor, bias, cout: int) -> torch.Tensor:
+    """nn.Conv2d(k=4, stride=2, padding=1) on an NHWC bf16 tensor [B,H,W,Cin] -> [B,H/2,W/2,cout]."""
+    return ops.conv2x2(space_to_depth_pad1(x), w_fwd, bias, cout, 0)
+
+
+def conv4x4_s2_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int, bias=None) -> torch.Tensor:
+    """Input gradient of conv4x4_s2 (= nn.ConvTranspose2d(k=4, stride=2, padding=1) with weight [Cout,Cin,4,4]):
+    NHWC [B,H/2,W/2,Cout] -> [B,H,W,cin].  ``bias`` ([cin]) is the transposed convolution's bias: replicated over the
+    four sub-pixel positions it is added by the kernel's epilogue."""
+    b4 = None if bias is None else bias.float().repeat(4).contiguous()
+    return depth_to_space_unpad1(ops.conv2x2(dy, w_dgrad, b4, 4 * cin, 1))

@@ -1,0 +1,100 @@
+"""4x4 stride-2 convolution and transposed convolution on the 2x2-tap MFMA kernel (the
+reference has no such layer, so torch's own operators on bf16-rounded operands are the yardstick).  bf16-stored
+outputs: 4e-3 max-norm relative, as for the 3x3 kernel."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rb(a):
+    return a.to(BF).float()
+
+
+def test_space_to_depth_round_trip():
+    from stain2stain_amd import pix2pix as P
+    x = torch.arange(2 * 6 * 8 * 8, dtype=torch.float32, device=DEV).view(2, 6, 8, 8).to(BF)
+    xs = P.space_to_depth_pad1(x)
+    assert xs.shape == (2, 4, 5, 32)
+    assert torch.equal(P.depth_to_space_unpad1(xs), x)
+    assert torch.equal(xs[:, 1, 1, 3 * 8:], x[:, 2, 2, :])          # (r,s) = (1,1) of cell (1,1) is xpad[3,3] = x[2,2]
+    assert float(xs[:, 0, :, :16].abs().max()) == 0.0                 # r = 0 of the first cell row is the zero border
+
+
+CASES = [  # B, H, W, Cin, Cout
+    (2, 16, 16, 8, 64),        # image layer (RGB padded to 8 channels)
+    (2, 32, 64, 64, 128),      # wide map, 128-channel tile
+    (1, 20, 12, 24, 40),       # ragged: K = 96 (3 chunks), Cout tail, W tail in the narrow tile
+    (3, 8, 8, 128, 256),
+    (2, 2, 2, 64, 64),         # innermost levels: 2x2 -> 1x1
+    (1, 66, 36, 16, 72),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv4x4_stride2_forward_and_input_gradient(case):
+    from stain2stain_amd import pix2pix as P
+    B, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(40 + cin)
+    x = rb(torch.rand(B, cin, H, W, generator=g) * 2 - 1).requires_grad_(True)
+    w = rb((torch.rand(cout, cin, 4, 4, generator=g) * 2 - 1) * (3.0 / (16 * cin)) ** 0.5)
+    b = torch.rand(cout, generator=g) - 0.5
+    dy = rb(torch.rand(B, cout, H // 2, W // 2, generator=g) - 0.5)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    (ref * dy).sum().backward()
+    wf, wd = P.pack_conv4x4_s2(w.to(DEV))
+    y = P.conv4x4_s2(nhwc(x.detach()), wf, b.to(DEV), cout)
+    assert y.shape == (B, H // 2, W // 2, cout)
+    assert relerr(nchw(y), ref.detach()) < 4e-3
+    dx = P.conv4x4_s2_dgrad(nhwc(dy), wd, cin)
+    assert dx.shape == (B, H, W, cin)
+    assert relerr(nchw(dx), x.grad) < 4e-3
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 128, 64), (1, 1, 1, 64, 64), (2, 5, 7, 40, 24)])
+def test_conv_transpose4x4_stride2(case):
+    """nn.ConvTranspose2d(k=4, stride=2, padding=1) (the pix2pix decoder's up-convolution) = the data-gradient form."""
+    from stain2stain_amd import pix2pix as P
+    B, H, W, cin, cout = case                                   # transposed conv: cin -> cout, (H, W) -> (2H, 2W)
+    g = torch.Generator().manual_seed(50 + cin)
+    x = rb(torch.rand(B, cin, H, W, generator=g) * 2 - 1)
+    wt = rb((torch.rand(cin, cout, 4, 4, generator=g) * 2 - 1) * (3.0 / (4 * cin)) ** 0.5)   # ConvTranspose2d layout
+    b = torch.rand(cout, generator=g) - 0.5
+    ref = F.conv_transpose2d(x, wt, b, stride=2, padding=1)
+    _, wd = P.pack_conv4x4_s2(wt.to(DEV))                        # as the Conv2d weight [O = cin, C = cout, 4, 4]
+    y = P.conv4x4_s2_dgrad(nhwc(x), wd, cout, bias=b.to(DEV))
+    assert y.shape == (B, 2 * H, 2 * W, cout)
+    assert relerr(nchw(y), ref) < 4e-3
+
+
+def test_encoder_level_size_against_torch_on_device():
+    """A pix2pix encoder level at the headline batch (16 x 64 channels at 128x128 -> 128 channels at 64x64): forward on
+    two samples and the input gradient on two samples against torch's CPU convolution."""
+    from stain2stain_amd import pix2pix as P
+    g = torch.Generator(device=DEV).manual_seed(1984)
+    xs = (torch.rand(16, 128, 128, 64, device=DEV, generator=g) * 2 - 1).to(BF)
+    dys = (torch.rand(16, 64, 64, 128, device=DEV, generator=g) - 0.5).to(BF)
+    w = ((torch.rand(128, 64, 4, 4, device=DEV, generator=g) * 2 - 1) * (3.0 / 1024) ** 0.5).to(BF).float()
+    b = torch.rand(128, device=DEV, generator=g) - 0.5
+    wf, wd = P.pack_conv4x4_s2(w)
+    y = P.conv4x4_s2(xs, wf, b, 128)
+    dx = P.conv4x4_s2_dgrad(dys, wd, 64)
+    sel = [0, 15]
+    xc = xs[sel].float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.conv2d(xc, w.cpu(), b.cpu(), stride=2, padding=1)
+    (ref * dys[sel].float().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert relerr(nchw(y[sel]), ref.detach()) < 4e-3
+    assert relerr(nchw(dx[sel]), xc.grad) < 4e-3
