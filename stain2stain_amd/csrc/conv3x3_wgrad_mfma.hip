@@ -478,6 +478,174 @@ inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
   return 0;   // re-measured after the reduce kernel was widened: nine taps per workgroup win by 8% even at 64->64
 }
 
+// =========================================================================================================
+// 2x2-tap variant: weight gradient of conv2x2_dma16_kernel's pad = 0 form,
+//   dW[a*2+b][co][k] = sum_{n,i,j} dY[n][i][j][co] * X[n][i+a][j+b][k],   X is (H+1) x (W+1), dY is H x W,
+// i.e. of the 4x4 stride-2 convolution on the space-to-depth image.  Same staging (LDS-DMA, double-buffered, one
+// barrier per pixel tile), same transposed fragment reads, four accumulators instead of nine; the halo is
+// (TH+1) x (TW+1) and is never out of range for a tile inside the output.
+// =========================================================================================================
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = 4;
+  constexpr int NPX = TH * TW;
+  constexpr int HW_ = TW + 1, HR = TH + 1, HALO = HR * HW_;
+  constexpr int XROWS = (HALO + 31) / 32 * 32;
+  constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
+  constexpr int DYG = 2 * NPX / 16 / 4;
+  constexpr int XG = 2 * XROWS / 16 / 4;
+  constexpr int BUF = DY_BYTES + X_BYTES;
+  constexpr int KSTEPS = NPX / 16;
+  static_assert((2 * NPX / 16) % 4 == 0 && (2 * XROWS / 16) % 4 == 0, "DMA groups split evenly over 4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0;
+  const int Hi = a.H + 1, Wi = a.W + 1;
+  const int drow = lane >> 2, dslot = lane & 3;
+  const int zsplit = (int)blockIdx.z;
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  int dy_off[DYG], dy_py[DYG], dy_px[DYG];
+  bool dy_ok[DYG];
+#pragma unroll
+  for (int j = 0; j < DYG; ++j) {
+    const int grp = wave + 4 * j;
+    const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
+    const int co = co0 + half * 32 + dslot * 8;
+    dy_py[j] = px / TW; dy_px[j] = px - dy_py[j] * TW;
+    dy_ok[j] = co < a.Cout;
+    dy_off[j] = (dy_py[j] * a.W + dy_px[j]) * a.lddy + co;
+  }
+  const T* x_ptr[XG];
+  int x_off[XG], x_hy[XG], x_hx[XG];
+#pragma unroll
+  for (int j = 0; j < XG; ++j) {
+    const int grp = wave + 4 * j;
+    const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
+    const int ci = ci0 + half * 32 + dslot * 8;
+    x_hy[j] = px / HW_; x_hx[j] = px - x_hy[j] * HW_;
+    x_ptr[j] = (px < HALO && ci < cin) ? x0 + ci : nullptr;
+    x_off[j] = (x_hy[j] * Wi + x_hx[j]) * a.ld0;
+  }
+
+  auto dma_tile = [&](int tile, int buf) {
+    int bt = tile;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int img = bt / a.tilesY;
+    const int y0 = ty * TH, xs = tx * TW;
+    const long pixbase = (long)(img * a.H + y0) * a.W + xs;           // dY (output) pixel, wave-uniform
+    const long xbase = (long)(img * Hi + y0) * Wi + xs;               // X (input) pixel of the halo origin
+    const bool interior = y0 + TH <= a.H && xs + TW <= a.W;           // then the halo is inside the input too
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < DYG; ++j) {
+        const void* src = dy_ok[j] ? (const void*)(dy + pixbase * a.lddy + dy_off[j]) : (const void*)g_wgrad_zero_page;
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+      }
+#pragma unroll
+      for (int j = 0; j < XG; ++j) {
+        const void* src = x_ptr[j] ? (const void*)(x_ptr[j] + xbase * a.ld0 + x_off[j]) : (const void*)g_wgrad_zero_page;
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DYG; ++j) {
+        const int gy = y0 + dy_py[j], gx = xs + dy_px[j];
+        const void* src = g_wgrad_zero_page;
+        if (gy < a.H && gx < a.W && dy_ok[j]) src = dy + pixbase * a.lddy + dy_off[j];
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+      }
+#pragma unroll
+      for (int j = 0; j < XG; ++j) {
+        const int gy = y0 + x_hy[j], gx = xs + x_hx[j];
+        const void* src = g_wgrad_zero_page;
+        if (x_ptr[j] && gy < Hi && gx < Wi) src = x_ptr[j] + xbase * a.ld0 + x_off[j];
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+      }
+    }
+  };
+
+  int tile = zsplit;
+  int buf = 0;
+  if (tile < a.ntiles) dma_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; tile < a.ntiles; tile += a.S) {
+    if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);
+    const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int hoff = ((py + t / 2) * HW_ + px + t % 2) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (co < a.Cout && ci < cin)
+        a.part[(((long)zsplit * NT + t) * a.Cout + co) * cin + ci] = acc[t][j];
+    }
+  }
+}
+
+// out[i] (+)= sum_z part[z][i], i < n (n = 4 * Cout * K): the split slabs of the kernel above, folded in a fixed order
+__global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long n,
+                                                        int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f;
+  int z = 0;
+  for (; z + 1 < S; z += 2) { s0 += part[(long)z * n + i]; s1 += part[(long)(z + 1) * n + i]; }
+  if (z < S) s0 += part[(long)z * n + i];
+  const float v = s0 + s1;
+  out[i] = accumulate ? out[i] + v : v;
+}
+
+int conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  const int nt = B * cdiv(H, 8) * cdiv(W, 16);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
+  int s = 512 / mn;
+  if (s > 256) s = 256;
+  if (s > nt) s = nt;
+  if (s < 1) s = 1;
+  return s;
+}
+
 // one pixel tile = 8 rows x 16 columns (halo 10 x 18); this shape keeps the staging prefetch small
 // enough for two workgroups per CU (a 4 x 32 tile spills at that occupancy)
 int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
@@ -530,6 +698,49 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, grad_oihw,
                        a.S, Cout, c0 + c1, accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// ---- 2x2-tap weight gradient (row a13) --------------------------------------------------------------------------
+// grad2[tap a*2+b][Cout][cin] (+)= sum over the batch; dY is [B][H][W][Cout], X is [B][H+1][W+1][cin] (the pad = 0
+// operand of s2s_conv2x2_nhwc).  part: float[s2s_conv2x2_wgrad_splits()][4][Cout][cin].
+extern "C" int s2s_conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
+  return conv2x2_wgrad_splits(B, H, W, Cin, Cout);
+}
+
+extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin,
+                                      float* part, float* grad2, int accumulate, int B, int H, int W, void* stream) {
+  if (!dy || !x || !part || !grad2) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0) return S2S_ERR_SHAPE;
+  if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
+  WgradArgs a;
+  a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
+  a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
+  a.B = B; a.H = H; a.W = W;
+  a.S = conv2x2_wgrad_splits(B, H, W, cin, Cout);
+  a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
+  a.ntiles = B * a.tilesY * a.tilesX;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int TH = 8, TW = 16;
+  constexpr int XROWS = ((TH + 1) * (TW + 1) + 31) / 32 * 32;
+  constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
+  auto kern = conv2x2_wgrad_dma_kernel<TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(cdiv(cin, 64), cdiv(Cout, 64), a.S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  const long n = 4L * Cout * cin;
+  hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad2, a.S, n,
+                     accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

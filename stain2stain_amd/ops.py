@@ -646,3 +646,22 @@ def conv2x2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
                                _stream())
     _native.check(rc, "conv2x2")
     return y
+
+
+@_timed("conv2x2_wgrad_mfma")
+def conv2x2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad2: torch.Tensor, accumulate: bool = False) -> None:
+    """grad2[4][cout][cin] (+)= weight gradient of conv2x2(pad 0): dy [B,H,W,cout], x [B,H+1,W+1,cin], NHWC bf16."""
+    B, H, W, cout = dy.shape
+    cin = x.shape[3]
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or tuple(x.shape[:3]) != (B, H + 1, W + 1):
+        raise RuntimeError("stain2stain_amd: conv2x2_wgrad operand mismatch")
+    if tuple(grad2.shape) != (4, cout, cin):
+        raise RuntimeError("stain2stain_amd: conv2x2_wgrad gradient buffer has the wrong shape")
+    pdy, lddy = _nhwc(dy)
+    px, ldx = _nhwc(x)
+    s = _L().s2s_conv2x2_wgrad_splits(B, H, W, cin, cout)
+    _native.check(min(s, 0), "conv2x2_wgrad_splits")
+    part = torch.empty((s, 4, cout, cin), dtype=torch.float32, device=dy.device)
+    rc = _L().s2s_conv2x2_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), _f32(grad2), int(accumulate),
+                                     B, H, W, _stream())
+    _native.check(rc, "conv2x2_wgrad")

@@ -130,3 +130,21 @@ def conv4x4_s2_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int, bias=Non
     four sub-pixel positions it is added by the kernel's epilogue."""
     b4 = None if bias is None else bias.float().repeat(4).contiguous()
     return depth_to_space_unpad1(ops.conv2x2(dy, w_dgrad, b4, 4 * cin, 1))
+
+
+def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+    """Weight gradient of conv4x4_s2 in nn.Conv2d's layout [Cout,Cin,4,4] (fp32): dy [B,H/2,W/2,Cout], x [B,H,W,Cin]
+    NHWC bf16.  The kernel produces it per 2x2 tap over the space-to-depth channels; the re-ordering into OIHW is a
+    view permutation of that small tensor."""
+    cout, cin = dy.shape[3], x.shape[3]
+    g2 = torch.empty((4, cout, 4 * cin), dtype=torch.float32, device=dy.device)
+    ops.conv2x2_wgrad(dy, space_to_depth_pad1(x), g2)
+    # g2[(a,b)][o][(r,s,c)] -> w[o][c][2a+r][2b+s]
+    g = g2.view(2, 2, cout, 2, 2, cin).permute(2, 5, 0, 3, 1, 4).reshape(cout, cin, 4, 4)
+    if grad is None:
+        return g.contiguous()
+    if accumulate:
+        grad.add_(g)
+    else:
+        grad.copy_(g)
+    return grad

@@ -1,4 +1,4 @@
-"""4x4 stride-2 convolution and transposed convolution on the 2x2-tap MFMA kernel (the
+"""4x4 stride-2 convolution (forward, data and weight gradient) and transposed convolution on the 2x2-tap MFMA kernels (the
 reference has no such layer, so torch's own operators on bf16-rounded operands are the yardstick).  bf16-stored
 outputs: 4e-3 max-norm relative, as for the 3x3 kernel."""
 import pytest
@@ -62,6 +62,14 @@ def test_conv4x4_stride2_forward_and_input_gradient(case):
     dx = P.conv4x4_s2_dgrad(nhwc(dy), wd, cin)
     assert dx.shape == (B, H, W, cin)
     assert relerr(nchw(dx), x.grad) < 4e-3
+    wr = w.clone().requires_grad_(True)                            # weight gradient (fp32 output: 1e-4)
+    (F.conv2d(x.detach(), wr, None, stride=2, padding=1) * dy).sum().backward()
+    gw = P.conv4x4_s2_wgrad(nhwc(dy), nhwc(x.detach()))
+    assert gw.shape == (cout, cin, 4, 4)
+    assert relerr(gw.cpu(), wr.grad) < 1e-4
+    acc = torch.full_like(gw, 2.0)
+    P.conv4x4_s2_wgrad(nhwc(dy), nhwc(x.detach()), acc, accumulate=True)
+    assert relerr(acc.cpu() - 2.0, wr.grad) < 1e-4
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 64), (1, 1, 1, 64, 64), (2, 5, 7, 40, 24)])
@@ -98,3 +106,7 @@ def test_encoder_level_size_against_torch_on_device():
     (ref * dys[sel].float().cpu().permute(0, 3, 1, 2)).sum().backward()
     assert relerr(nchw(y[sel]), ref.detach()) < 4e-3
     assert relerr(nchw(dx[sel]), xc.grad) < 4e-3
+    gw = P.conv4x4_s2_wgrad(dys, xs)                               # sums over the whole batch
+    ref_gw = torch.nn.grad.conv2d_weight(xs.float().cpu().permute(0, 3, 1, 2).contiguous(), (128, 64, 4, 4),
+                                         dys.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=1)
+    assert relerr(gw.cpu(), ref_gw) < 1e-4
