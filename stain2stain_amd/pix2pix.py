@@ -148,3 +148,103 @@ def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = Non
     else:
         grad.copy_(g)
     return grad
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# nn.Module faces of the two layers (signatures and state-dict keys of nn.Conv2d / nn.ConvTranspose2d with
+# kernel_size=4, stride=2, padding=1).  Activations are bf16 NHWC in memory (logical NCHW in torch.channels_last);
+# weights stay fp32 masters and are packed into the MFMA operand layouts whenever they change.
+# ------------------------------------------------------------------------------------------------------------------
+class _PackCache:
+    def __init__(self):
+        self.key, self.packed = None, None
+
+    def get(self, w: torch.Tensor):
+        key = (w.data_ptr(), w._version, w.device)
+        if key != self.key:
+            self.packed, self.key = pack_conv4x4_s2(w), key
+        return self.packed
+
+
+def _to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("stain2stain_amd: the pix2pix layers run on the GPU only (no CPU fallback)")
+    return x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+class _Conv4x4S2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        xs = _to_nhwc_bf16(x)
+        wf, wd = cache.get(weight)
+        y = conv4x4_s2(xs, wf, bias, weight.shape[0])
+        ctx.save_for_backward(xs)
+        ctx.wd, ctx.cin, ctx.has_bias, ctx.xdtype = wd, weight.shape[1], bias is not None, x.dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xs,) = ctx.saved_tensors
+        g = _to_nhwc_bf16(gy)
+        dx = conv4x4_s2_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
+        dw = conv4x4_s2_wgrad(g, xs)
+        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class _ConvT4x4S2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        xs = _to_nhwc_bf16(x)
+        wf, wd = cache.get(weight)                      # weight [Cin, Cout, 4, 4] read as the Conv2d weight [O, C, 4, 4]
+        y = conv4x4_s2_dgrad(xs, wd, weight.shape[1], bias=bias)
+        ctx.save_for_backward(xs)
+        ctx.wf, ctx.cin, ctx.has_bias, ctx.xdtype = wf, weight.shape[0], bias is not None, x.dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xs,) = ctx.saved_tensors
+        g = _to_nhwc_bf16(gy)                           # [B, 2H, 2W, Cout]: the "input" of the equivalent convolution
+        dx = conv4x4_s2(g, ctx.wf, None, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
+        dw = conv4x4_s2_wgrad(xs, g)                    # [O = Cin, C = Cout, 4, 4] = nn.ConvTranspose2d's layout
+        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class _Layer4x4(nn.Module):
+    def __init__(self, w_shape, n_bias, bias: bool, fan_in: int):
+        super().__init__()
+        if w_shape[0] % 8 or w_shape[1] % 8:
+            raise ValueError("channel counts must be multiples of 8 (pad the image to 8 channels)")
+        self.weight = nn.Parameter(torch.empty(*w_shape, 4, 4))
+        self.bias = nn.Parameter(torch.empty(n_bias)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)                  # nn.Conv2d's default initialisation
+        if bias:
+            bound = 1.0 / fan_in ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._cache = _PackCache()
+
+
+class Conv4x4Stride2(_Layer4x4):
+    """``nn.Conv2d(in_channels, out_channels, kernel_size=4, stride=2, padding=1)`` (pix2pix encoder / PatchGAN layer)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__((out_channels, in_channels), out_channels, bias, in_channels * 16)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != self.weight.shape[1] or x.shape[2] % 2 or x.shape[3] % 2:
+            raise ValueError(f"expected [B, {self.weight.shape[1]}, even H, even W], got {tuple(x.shape)}")
+        return _Conv4x4S2.apply(x, self.weight, self.bias, self._cache)
+
+
+class ConvTranspose4x4Stride2(_Layer4x4):
+    """``nn.ConvTranspose2d(in_channels, out_channels, kernel_size=4, stride=2, padding=1)`` (pix2pix decoder layer)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__((in_channels, out_channels), out_channels, bias, out_channels * 16)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != self.weight.shape[0]:
+            raise ValueError(f"expected [B, {self.weight.shape[0]}, H, W], got {tuple(x.shape)}")
+        return _ConvT4x4S2.apply(x, self.weight, self.bias, self._cache)

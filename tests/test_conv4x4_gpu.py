@@ -110,3 +110,39 @@ def test_encoder_level_size_against_torch_on_device():
     ref_gw = torch.nn.grad.conv2d_weight(xs.float().cpu().permute(0, 3, 1, 2).contiguous(), (128, 64, 4, 4),
                                          dys.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=1)
     assert relerr(gw.cpu(), ref_gw) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["conv", "transposed"])
+def test_modules_match_torch_layers_through_autograd(kind):
+    """Conv4x4Stride2 / ConvTranspose4x4Stride2 against nn.Conv2d / nn.ConvTranspose2d (k=4, s=2, p=1) with the same
+    parameters on bf16-rounded inputs: output and input gradient 4e-3 (bf16-stored), parameter gradients 1e-3 (fp32
+    sums of bf16 operands; the upstream gradient is rounded to bf16 on the way in)."""
+    from stain2stain_amd.pix2pix import Conv4x4Stride2, ConvTranspose4x4Stride2
+    g = torch.Generator().manual_seed(77)
+    if kind == "conv":
+        mine, ref = Conv4x4Stride2(16, 40).to(DEV), torch.nn.Conv2d(16, 40, 4, 2, 1)
+        x = rb(torch.rand(2, 16, 12, 20, generator=g) * 2 - 1)
+    else:
+        mine, ref = ConvTranspose4x4Stride2(24, 16).to(DEV), torch.nn.ConvTranspose2d(24, 16, 4, 2, 1)
+        x = rb(torch.rand(2, 24, 6, 10, generator=g) * 2 - 1)
+    assert set(mine.state_dict()) == set(ref.state_dict())
+    assert all(mine.state_dict()[k].shape == v.shape for k, v in ref.state_dict().items())
+    with torch.no_grad():
+        for k, v in ref.state_dict().items():
+            v.copy_(rb(mine.state_dict()[k].cpu()))
+        mine.load_state_dict(ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    out_ref = ref(xr)
+    cot = rb(torch.rand(out_ref.shape, generator=g) - 0.5)
+    (out_ref * cot).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    out = mine(xg)
+    (out.float() * cot.to(DEV)).sum().backward()
+    assert relerr(out.float().cpu(), out_ref.detach()) < 4e-3
+    assert relerr(xg.grad.cpu(), xr.grad) < 4e-3
+    assert relerr(mine.weight.grad.cpu(), ref.weight.grad) < 1e-3
+    assert relerr(mine.bias.grad.cpu(), ref.bias.grad) < 1e-3
+    # the packed operands follow the master weights
+    with torch.no_grad():
+        mine.weight.mul_(0.5); ref.weight.mul_(0.5)
+    assert relerr(mine(xg).float().cpu(), ref(xr).detach()) < 4e-3
