@@ -233,6 +233,11 @@ int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int
 int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout);
 int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, void* y,
                      int ldy, float* stat_part, int B, int H, int W, int Cout, int pad, void* stream);
+/* nn.Conv2d(k=4, stride=1, padding=1) of the PatchGAN's last two layers (pad = 1, input (H+1) x (W+1)) and its data
+ * gradient (pad = 2, input (H-1) x (W-1), taps flipped by the packing) on the same loop with 16 taps.
+ * w_packed: bf16 [ceil(cin/32)][tap kh*4+kw][Cout][32]. */
+int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, void* y,
+                       int ldy, float* stat_part, int B, int H, int W, int Cout, int pad, void* stream);
 /* weight gradient of the pad = 0 form: grad2[tap a*2+b][Cout][cin] (+)= sum_{n,i,j} dY[n][i][j][:] x X[n][i+a][j+b][:],
  * dY [B][H][W][Cout], X [B][H+1][W+1][cin]; part: float[s2s_conv2x2_wgrad_splits()][4][Cout][cin] scratch. */
 int s2s_conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout);

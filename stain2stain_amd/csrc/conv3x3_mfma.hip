@@ -905,18 +905,23 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
 }
 
 // =========================================================================================================
-// 2x2-tap variant of the loop above.  A 4x4 stride-2 pad-1 convolution is a 2x2
-// "valid" convolution over the space-to-depth image of the padded input (K = 4 taps x 4*Cin, no wasted MACs), and its
-// data gradient / the 4x4 stride-2 transposed convolution is the same loop with the taps flipped and the origin
-// shifted by one: PAD = 0 reads input (i + a, j + b) and has Hin = H + 1, PAD = 1 reads (i + a - 1, j + b - 1) and has
-// Hin = H - 1 (a.H, a.W are the OUTPUT size, as everywhere).  Same halo image, weight ring, swizzle, operand order and
-// epilogue as conv3x3_dma16_kernel; weights packed [chunk][tap a*2+b][Cout][32].  One source tensor.
+// KS x KS-tap variants of the loop above with an output size different from the input's (SURVEY.md section 8, row
+// a13): y[i][j] = sum_{a,b < KS} W[a][b] x[i + a - PAD][j + b - PAD], input (H + KS - 1 - 2 PAD) squared-ish, a.H / a.W
+// the OUTPUT size as everywhere.
+//   KS = 2: a 4x4 stride-2 pad-1 convolution is a 2x2 "valid" convolution (PAD = 0, Hin = H + 1) over the
+//           space-to-depth image of the padded input (K = 4 taps x 4*Cin, no wasted MACs); its data gradient / the 4x4
+//           stride-2 transposed convolution is the same loop with flipped taps and PAD = 1 (Hin = H - 1).
+//   KS = 4: the PatchGAN's 4x4 stride-1 pad-1 layers (PAD = 1, Hin = H + 1) and their data gradient (PAD = 2,
+//           Hin = H - 1).
+// Same halo image, weight ring, swizzle, operand order and epilogue as conv3x3_dma16_kernel; weights packed
+// [chunk][tap a*KS+b][Cout][32].  One source tensor.
 // =========================================================================================================
-template <int TH, int TW, int BN, int WM, int WN, int NS, int PAD>
-__global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
+template <int TH, int TW, int BN, int WM, int WN, int NS, int KS, int PAD>
+__global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   using T = bf16_t;
-  constexpr int TAPS = 4;
-  constexpr int HP = TW + 4, HH_ = TH + 1, ROWS = HH_ * HP;
+  constexpr int TAPS = KS * KS;
+  static_assert(KS >= 2 && KS <= 5, "the halo row has four spare columns");
+  constexpr int HP = TW + 4, HH_ = TH + KS - 1, ROWS = HH_ * HP;
   constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + 3) / 4;
   constexpr int A_BYTES = HG * 4 * 1024;
   constexpr int BG = BN / 64;
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
   const int img = bt / a.tilesY;
   const int y0 = ty * TH, x0p = tx * TW;
   const int n0 = blockIdx.y * BN;
-  const int Hi = PAD ? a.H - 1 : a.H + 1, Wi = PAD ? a.W - 1 : a.W + 1;
+  const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;
 
   const int drow = lane >> 2, dslot = lane & 3;
   int apix[HG], apc[HG];
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
     const int row = (wave + 4 * j) * 16 + drow;
     const int hy = row / HP, hx = row - hy * HP;
     const int gy = y0 - PAD + hy, gx = x0p - PAD + hx;
-    apix[j] = (row < ROWS && hx < TW + 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? (img * Hi + gy) * Wi + gx : -1;
+    apix[j] = (row < ROWS && hx < TW + KS - 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? (img * Hi + gy) * Wi + gx : -1;
     apc[j] = (dslot ^ ((-(hx >> 2)) & 3)) * 8;
   }
   const char* wptr[BG];
@@ -980,11 +985,11 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
       wptr[j] += wstep[j];
     }
   };
-  int aofs[RB][2];
+  int aofs[RB][KS];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int kw = 0; kw < 2; ++kw) {
+    for (int kw = 0; kw < KS; ++kw) {
       const int px = rb * 16 + cl + kw;
       aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ ((-(px >> 2)) & 3)) << 4);
     }
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
 
   auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
     constexpr int tap = decltype(tapc)::value;
-    constexpr int kh = tap / 2, kw = tap % 2;
+    constexpr int kh = tap / KS, kw = tap % KS;
     bf16x8 af[MI], bfr[NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   };
   dma_halo(0);
-  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // nchunk * 4 >= 3 slabs always exist
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // nchunk * TAPS >= 3 slabs always exist
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -1057,16 +1062,16 @@ __global__ __launch_bounds__(256, 2) void conv2x2_dma16_kernel(Conv3x3Args a) {
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int PAD>
-int launch_conv2x2(Conv3x3Args& a, hipStream_t s) {
+template <int TH, int TW, int BN, int WM, int WN, int KS, int PAD>
+int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   constexpr int NS = 4;
-  constexpr int ROWS = (TH + 1) * (TW + 4);
+  constexpr int ROWS = (TH + KS - 1) * (TW + 4);
   constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
   constexpr int lds = 2 * HG * 4 * 1024 + NS * BN * 64;      // the epilogue stages inside this (static_assert there)
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
-  auto kern = conv2x2_dma16_kernel<TH, TW, BN, WM, WN, NS, PAD>;
+  auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -1433,9 +1438,38 @@ extern "C" int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wide = W > 16, big = Cout > 64;
   if (pad == 0) {
-    if (wide) return big ? launch_conv2x2<8, 32, 128, 2, 2, 0>(a, s) : launch_conv2x2<8, 32, 64, 4, 1, 0>(a, s);
-    return big ? launch_conv2x2<8, 16, 128, 2, 2, 0>(a, s) : launch_conv2x2<8, 16, 64, 2, 2, 0>(a, s);
+    if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0>(a, s);
+    return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0>(a, s);
   }
-  if (wide) return big ? launch_conv2x2<8, 32, 128, 2, 2, 1>(a, s) : launch_conv2x2<8, 32, 64, 4, 1, 1>(a, s);
-  return big ? launch_conv2x2<8, 16, 128, 2, 2, 1>(a, s) : launch_conv2x2<8, 16, 64, 2, 2, 1>(a, s);
+  if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1>(a, s);
+  return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1>(a, s);
+}
+
+// ---- 4x4 stride-1 convolution (row a13: the PatchGAN discriminator's last two layers) -----------------------------
+// Output H x W; pad 1: nn.Conv2d(k=4, stride=1, padding=1), input (H+1) x (W+1); pad 2: its data gradient, input
+// (H-1) x (W-1), taps flipped by the packing.  w_packed: bf16 [ceil(Cin/32)][16][Cout][32].
+extern "C" int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
+                                  void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
+                                  void* stream) {
+  if (!x || !w_packed || !y) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8)) return S2S_ERR_SHAPE;
+  if (pad != 1 && pad != 2) return S2S_ERR_SHAPE;
+  if (pad == 2 && (H < 2 || W < 2)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
+  Conv3x3Args a;
+  a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
+  a.ep_scale = a.ep_shift = nullptr;
+  a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
+  a.tilesX = a.tilesY = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wide = W > 16, big = Cout > 64;      // 4-row tiles on wide maps: two workgroups per CU with the 7-row halo
+  if (pad == 1) {
+    if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 1>(a, s);
+    return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 1>(a, s);
+  }
+  if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 2>(a, s);
+  return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 2>(a, s);
 }

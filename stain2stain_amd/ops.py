@@ -665,3 +665,25 @@ def conv2x2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad2: torch.Tensor, accumu
     rc = _L().s2s_conv2x2_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), _f32(grad2), int(accumulate),
                                      B, H, W, _stream())
     _native.check(rc, "conv2x2_wgrad")
+
+
+@_timed("conv4x4s1_mfma", lambda x, w_packed, bias, cout, pad, **kw: 2.0 * x.shape[0] * (x.shape[1] + (1 if pad == 2 else -1))
+        * (x.shape[2] + (1 if pad == 2 else -1)) * cout * 16 * x.shape[3])
+def conv4x4s1(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pad: int) -> torch.Tensor:
+    """4x4 stride-1 convolution on the MFMA loop (row a13, PatchGAN): pad 1 -> output (Hi-1) x (Wi-1)
+    (nn.Conv2d(k=4, s=1, p=1)); pad 2 -> output (Hi+1) x (Wi+1) (its data gradient, flipped packing).
+    x: NHWC bf16 view; w_packed: bf16 [cin/32][16][cout][32]."""
+    B, Hi, Wi, cin = x.shape
+    if pad not in (1, 2):
+        raise RuntimeError("stain2stain_amd: conv4x4s1 pad must be 1 or 2")
+    H, W = (Hi + 1, Wi + 1) if pad == 2 else (Hi - 1, Wi - 1)
+    if x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16:
+        raise RuntimeError("stain2stain_amd: conv4x4s1 runs in bf16 only")
+    if w_packed.numel() != ((cin + 31) // 32) * 16 * cout * 32:
+        raise RuntimeError("stain2stain_amd: conv4x4s1 packed weight has the wrong size")
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device)
+    rc = _L().s2s_conv4x4s1_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), y.data_ptr(), cout, 0, B, H, W, cout,
+                                 int(pad), _stream())
+    _native.check(rc, "conv4x4s1")
+    return y

@@ -99,7 +99,7 @@ def depth_to_space_unpad1(xs: torch.Tensor) -> torch.Tensor:
 
 
 def _chunks32(m: torch.Tensor) -> torch.Tensor:
-    """[rows, 4 taps, K] fp32 -> bf16 [ceil(K/32)][4][rows][32] (the slab order of the kernel's weight ring)."""
+    """[rows, taps, K] fp32 -> bf16 [ceil(K/32)][taps][rows][32] (the slab order of the kernel's weight ring)."""
     rows, taps, K = m.shape
     kp = (K + 31) // 32 * 32
     if kp != K:
@@ -149,6 +149,25 @@ def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = Non
         grad.copy_(g)
     return grad
 
+
+
+def pack_conv4x4_s1(w: torch.Tensor):
+    """nn.Conv2d(k=4, s=1, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv4x4s1_nhwc:
+    [chunk][tap kh*4+kw][rows][32] with rows = Cout, k = Cin forward and rows = Cin, k = Cout, taps flipped backward."""
+    Cout, Cin = w.shape[:2]
+    wf = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, 16, Cin)                    # o, (kh,kw), c
+    wd = w.detach().float().flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 16, Cout)         # c, (3-kh,3-kw), o
+    return _chunks32(wf), _chunks32(wd)
+
+
+def conv4x4_s1(x: torch.Tensor, w_fwd: torch.Tensor, bias, cout: int) -> torch.Tensor:
+    """nn.Conv2d(k=4, stride=1, padding=1) on an NHWC bf16 tensor [B,H,W,Cin] -> [B,H-1,W-1,cout]."""
+    return ops.conv4x4s1(x, w_fwd, bias, cout, 1)
+
+
+def conv4x4_s1_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int) -> torch.Tensor:
+    """Input gradient of conv4x4_s1: [B,H-1,W-1,Cout] -> [B,H,W,cin]."""
+    return ops.conv4x4s1(dy, w_dgrad, None, cin, 2)
 
 # ------------------------------------------------------------------------------------------------------------------
 # nn.Module faces of the two layers (signatures and state-dict keys of nn.Conv2d / nn.ConvTranspose2d with

@@ -146,3 +146,25 @@ def test_modules_match_torch_layers_through_autograd(kind):
     with torch.no_grad():
         mine.weight.mul_(0.5); ref.weight.mul_(0.5)
     assert relerr(mine(xg).float().cpu(), ref(xr).detach()) < 4e-3
+
+
+@pytest.mark.parametrize("case", [(2, 17, 33, 64, 128), (1, 9, 12, 24, 8), (2, 32, 32, 256, 512), (3, 5, 40, 40, 72)])
+def test_conv4x4_stride1_forward_and_input_gradient(case):
+    """nn.Conv2d(k=4, stride=1, padding=1) (the PatchGAN's last two layers; Cout = 1 is padded to 8) on the 16-tap form
+    of the loop, and its data gradient."""
+    from stain2stain_amd import pix2pix as P
+    B, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(60 + cin)
+    x = rb(torch.rand(B, cin, H, W, generator=g) * 2 - 1).requires_grad_(True)
+    w = rb((torch.rand(cout, cin, 4, 4, generator=g) * 2 - 1) * (3.0 / (16 * cin)) ** 0.5)
+    b = torch.rand(cout, generator=g) - 0.5
+    ref = F.conv2d(x, w, b, stride=1, padding=1)
+    dy = rb(torch.rand(ref.shape, generator=g) - 0.5)
+    (ref * dy).sum().backward()
+    wf, wd = P.pack_conv4x4_s1(w.to(DEV))
+    y = P.conv4x4_s1(nhwc(x.detach()), wf, b.to(DEV), cout)
+    assert y.shape == (B, H - 1, W - 1, cout)
+    assert relerr(nchw(y), ref.detach()) < 4e-3
+    dx = P.conv4x4_s1_dgrad(nhwc(dy), wd, cin)
+    assert dx.shape == (B, H, W, cin)
+    assert relerr(nchw(dx), x.grad) < 4e-3
