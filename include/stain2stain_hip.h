@@ -238,6 +238,11 @@ int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_p
  * w_packed: bf16 [ceil(cin/32)][tap kh*4+kw][Cout][32]. */
 int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, void* y,
                        int ldy, float* stat_part, int B, int H, int W, int Cout, int pad, void* stream);
+/* weight gradient of the pad = 1 form: grad16[tap kh*4+kw][Cout][cin] (+)= sum over the batch, dY [B][H][W][Cout],
+ * X [B][H+1][W+1][cin]; part: float[s2s_conv4x4s1_wgrad_splits()][16][Cout][cin] scratch. */
+int s2s_conv4x4s1_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin,
+                             float* part, float* grad16, int accumulate, int B, int H, int W, void* stream);
 /* weight gradient of the pad = 0 form: grad2[tap a*2+b][Cout][cin] (+)= sum_{n,i,j} dY[n][i][j][:] x X[n][i+a][j+b][:],
  * dY [B][H][W][Cout], X [B][H+1][W+1][cin]; part: float[s2s_conv2x2_wgrad_splits()][4][Cout][cin] scratch. */
 int s2s_conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout);

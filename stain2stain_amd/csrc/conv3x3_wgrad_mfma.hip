@@ -623,6 +623,134 @@ __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) 
   }
 }
 
+// KS x KS taps, stride 1 (row a13: the PatchGAN's 4x4 stride-1 pad-1 layers, KS = 4, PAD = 1):
+//   dW[kh*KS+kw][co][ci] = sum_{n,i,j} dY[n][i][j][co] * X[n][i+kh-PAD][j+kw-PAD][ci],   X is (H+KS-1-2PAD) wide.
+// Sixteen 32x32 accumulators do not fit a wave, so the kernel rows go to KS workgroups (blockIdx.z = split*KS + kh,
+// the NT = 3 idea of the 3x3 kernel): each accumulates the KS taps of its row and stages only the TH halo rows that
+// row reads.  Every lane bounds-tests its halo pixel (the padded border is part of most tiles here).
+template <int TH, int TW, int KS, int PAD>
+__global__ __launch_bounds__(256, 2) void convkxk_wgrad_rows_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = KS;
+  constexpr int NPX = TH * TW;
+  constexpr int HW_ = TW + KS - 1, HR = TH, HALO = HR * HW_;
+  constexpr int XROWS = (HALO + 31) / 32 * 32;
+  constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
+  constexpr int DYG = 2 * NPX / 16 / 4;
+  constexpr int XG = 2 * XROWS / 16 / 4;
+  constexpr int BUF = DY_BYTES + X_BYTES;
+  constexpr int KSTEPS = NPX / 16;
+  static_assert((2 * NPX / 16) % 4 == 0 && (2 * XROWS / 16) % 4 == 0, "DMA groups split evenly over 4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0;
+  const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;
+  const int drow = lane >> 2, dslot = lane & 3;
+  const int kh = (int)(blockIdx.z % KS), zsplit = (int)(blockIdx.z / KS);
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  int dy_off[DYG], dy_py[DYG], dy_px[DYG];
+  bool dy_ok[DYG];
+#pragma unroll
+  for (int j = 0; j < DYG; ++j) {
+    const int grp = wave + 4 * j;
+    const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
+    const int co = co0 + half * 32 + dslot * 8;
+    dy_py[j] = px / TW; dy_px[j] = px - dy_py[j] * TW;
+    dy_ok[j] = co < a.Cout;
+    dy_off[j] = (dy_py[j] * a.W + dy_px[j]) * a.lddy + co;
+  }
+  int x_ch[XG], x_hy[XG], x_hx[XG];
+#pragma unroll
+  for (int j = 0; j < XG; ++j) {
+    const int grp = wave + 4 * j;
+    const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
+    const int ci = ci0 + half * 32 + dslot * 8;
+    x_hy[j] = px / HW_; x_hx[j] = px - x_hy[j] * HW_;
+    x_ch[j] = (px < HALO && ci < cin) ? ci : -1;
+  }
+
+  auto dma_tile = [&](int tile, int buf) {
+    int bt = tile;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int img = bt / a.tilesY;
+    const int y0 = ty * TH, xs = tx * TW;
+    const long pixbase = (long)(img * a.H + y0) * a.W + xs;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < DYG; ++j) {
+      const int gy = y0 + dy_py[j], gx = xs + dy_px[j];
+      const void* src = g_wgrad_zero_page;
+      if (gy < a.H && gx < a.W && dy_ok[j]) src = dy + pixbase * a.lddy + dy_off[j];
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < XG; ++j) {
+      const int gy = y0 + kh - PAD + x_hy[j], gx = xs - PAD + x_hx[j];
+      const void* src = g_wgrad_zero_page;
+      if (x_ch[j] >= 0 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+        src = x0 + ((long)(img * Hi + gy) * Wi + gx) * a.ld0 + x_ch[j];
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+    }
+  };
+
+  int tile = zsplit;
+  int buf = 0;
+  if (tile < a.ntiles) dma_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; tile < a.ntiles; tile += a.S) {
+    if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);
+    const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int hoff = (py * HW_ + px + t) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = kh * KS + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (co < a.Cout && ci < cin)
+        a.part[(((long)zsplit * (KS * KS) + tap) * a.Cout + co) * cin + ci] = acc[t][j];
+    }
+  }
+}
+
 // out[i] (+)= sum_z part[z][i], i < n (n = 4 * Cout * K): the split slabs of the kernel above, folded in a fixed order
 __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long n,
                                                         int accumulate) {
@@ -740,6 +868,56 @@ extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   const long n = 4L * Cout * cin;
   hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad2, a.S, n,
+                     accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// ---- 4x4 stride-1 weight gradient (row a13, PatchGAN layers) ------------------------------------------------------
+// grad16[tap kh*4+kw][Cout][cin] (+)= sum over the batch; dY is [B][H][W][Cout], X is [B][H+1][W+1][cin] (pad 1).
+// part: float[s2s_conv4x4s1_wgrad_splits()][16][Cout][cin].
+extern "C" int s2s_conv4x4s1_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
+  const int nt = B * cdiv(H, 8) * cdiv(W, 16);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * 4;        // four kernel rows per (co, ci) tile
+  int s = 512 / mn;
+  if (s > 128) s = 128;
+  if (s > nt) s = nt;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin,
+                                        float* part, float* grad16, int accumulate, int B, int H, int W,
+                                        void* stream) {
+  if (!dy || !x || !part || !grad16) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0) return S2S_ERR_SHAPE;
+  if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
+  WgradArgs a;
+  a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
+  a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
+  a.B = B; a.H = H; a.W = W;
+  a.S = s2s_conv4x4s1_wgrad_splits(B, H, W, cin, Cout);
+  a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
+  a.ntiles = B * a.tilesY * a.tilesX;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int TH = 8, TW = 16, KS = 4;
+  constexpr int XROWS = (TH * (TW + KS - 1) + 31) / 32 * 32;
+  constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
+  auto kern = convkxk_wgrad_rows_kernel<TH, TW, KS, 1>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return S2S_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(cdiv(cin, 64), cdiv(Cout, 64), a.S * KS);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  const long n = 16L * Cout * cin;
+  hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad16, a.S, n,
                      accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;

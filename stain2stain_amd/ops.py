@@ -687,3 +687,22 @@ def conv4x4s1(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                                  int(pad), _stream())
     _native.check(rc, "conv4x4s1")
     return y
+
+
+@_timed("conv4x4s1_wgrad_mfma")
+def conv4x4s1_wgrad(dy: torch.Tensor, x: torch.Tensor, grad16: torch.Tensor, accumulate: bool = False) -> None:
+    """grad16[16][cout][cin] (+)= weight gradient of conv4x4s1(pad 1): dy [B,H,W,cout], x [B,H+1,W+1,cin], NHWC bf16."""
+    B, H, W, cout = dy.shape
+    cin = x.shape[3]
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or tuple(x.shape[:3]) != (B, H + 1, W + 1):
+        raise RuntimeError("stain2stain_amd: conv4x4s1_wgrad operand mismatch")
+    if tuple(grad16.shape) != (16, cout, cin):
+        raise RuntimeError("stain2stain_amd: conv4x4s1_wgrad gradient buffer has the wrong shape")
+    pdy, lddy = _nhwc(dy)
+    px, ldx = _nhwc(x)
+    s = _L().s2s_conv4x4s1_wgrad_splits(B, H, W, cin, cout)
+    _native.check(min(s, 0), "conv4x4s1_wgrad_splits")
+    part = torch.empty((s, 16, cout, cin), dtype=torch.float32, device=dy.device)
+    rc = _L().s2s_conv4x4s1_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), _f32(grad16), int(accumulate),
+                                       B, H, W, _stream())
+    _native.check(rc, "conv4x4s1_wgrad")

@@ -169,19 +169,27 @@ def conv4x4_s1_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int) -> torch
     """Input gradient of conv4x4_s1: [B,H-1,W-1,Cout] -> [B,H,W,cin]."""
     return ops.conv4x4s1(dy, w_dgrad, None, cin, 2)
 
+
+def conv4x4_s1_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of conv4x4_s1 in nn.Conv2d's layout [Cout,Cin,4,4] (fp32): dy [B,H-1,W-1,Cout], x [B,H,W,Cin]."""
+    cout, cin = dy.shape[3], x.shape[3]
+    g16 = torch.empty((16, cout, cin), dtype=torch.float32, device=dy.device)
+    ops.conv4x4s1_wgrad(dy, x, g16)
+    return g16.view(4, 4, cout, cin).permute(2, 3, 0, 1).contiguous()
+
 # ------------------------------------------------------------------------------------------------------------------
-# nn.Module faces of the two layers (signatures and state-dict keys of nn.Conv2d / nn.ConvTranspose2d with
-# kernel_size=4, stride=2, padding=1).  Activations are bf16 NHWC in memory (logical NCHW in torch.channels_last);
+# nn.Module faces of the layers (signatures and state-dict keys of nn.Conv2d / nn.ConvTranspose2d with
+# kernel_size=4, padding=1, stride 2 or - PatchGAN - 1).  Activations are bf16 NHWC in memory (logical NCHW in torch.channels_last);
 # weights stay fp32 masters and are packed into the MFMA operand layouts whenever they change.
 # ------------------------------------------------------------------------------------------------------------------
 class _PackCache:
-    def __init__(self):
-        self.key, self.packed = None, None
+    def __init__(self, pack=None):
+        self.key, self.packed, self.pack = None, None, pack
 
     def get(self, w: torch.Tensor):
         key = (w.data_ptr(), w._version, w.device)
         if key != self.key:
-            self.packed, self.key = pack_conv4x4_s2(w), key
+            self.packed, self.key = (self.pack or pack_conv4x4_s2)(w), key
         return self.packed
 
 
@@ -267,3 +275,37 @@ class ConvTranspose4x4Stride2(_Layer4x4):
         if x.dim() != 4 or x.shape[1] != self.weight.shape[0]:
             raise ValueError(f"expected [B, {self.weight.shape[0]}, H, W], got {tuple(x.shape)}")
         return _ConvT4x4S2.apply(x, self.weight, self.bias, self._cache)
+
+
+class _Conv4x4S1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        xs = _to_nhwc_bf16(x)
+        wf, wd = cache.get(weight)
+        y = conv4x4_s1(xs, wf, bias, weight.shape[0])
+        ctx.save_for_backward(xs)
+        ctx.wd, ctx.cin, ctx.has_bias, ctx.xdtype = wd, weight.shape[1], bias is not None, x.dtype
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xs,) = ctx.saved_tensors
+        g = _to_nhwc_bf16(gy)
+        dx = conv4x4_s1_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
+        dw = conv4x4_s1_wgrad(g, xs)
+        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class Conv4x4Stride1(_Layer4x4):
+    """``nn.Conv2d(in_channels, out_channels, kernel_size=4, stride=1, padding=1)`` (the PatchGAN discriminator's last
+    two layers; pad the single output logit channel to 8 and read channel 0)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__((out_channels, in_channels), out_channels, bias, in_channels * 16)
+        self._cache = _PackCache(pack_conv4x4_s1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != self.weight.shape[1] or x.shape[2] < 2 or x.shape[3] < 2:
+            raise ValueError(f"expected [B, {self.weight.shape[1]}, H >= 2, W >= 2], got {tuple(x.shape)}")
+        return _Conv4x4S1.apply(x, self.weight, self.bias, self._cache)

@@ -112,14 +112,17 @@ def test_encoder_level_size_against_torch_on_device():
     assert relerr(gw.cpu(), ref_gw) < 1e-4
 
 
-@pytest.mark.parametrize("kind", ["conv", "transposed"])
+@pytest.mark.parametrize("kind", ["conv", "transposed", "stride1"])
 def test_modules_match_torch_layers_through_autograd(kind):
     """Conv4x4Stride2 / ConvTranspose4x4Stride2 against nn.Conv2d / nn.ConvTranspose2d (k=4, s=2, p=1) with the same
     parameters on bf16-rounded inputs: output and input gradient 4e-3 (bf16-stored), parameter gradients 1e-3 (fp32
     sums of bf16 operands; the upstream gradient is rounded to bf16 on the way in)."""
-    from stain2stain_amd.pix2pix import Conv4x4Stride2, ConvTranspose4x4Stride2
+    from stain2stain_amd.pix2pix import Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2
     g = torch.Generator().manual_seed(77)
-    if kind == "conv":
+    if kind == "stride1":
+        mine, ref = Conv4x4Stride1(32, 8).to(DEV), torch.nn.Conv2d(32, 8, 4, 1, 1)
+        x = rb(torch.rand(2, 32, 11, 14, generator=g) * 2 - 1)
+    elif kind == "conv":
         mine, ref = Conv4x4Stride2(16, 40).to(DEV), torch.nn.Conv2d(16, 40, 4, 2, 1)
         x = rb(torch.rand(2, 16, 12, 20, generator=g) * 2 - 1)
     else:
@@ -168,3 +171,8 @@ def test_conv4x4_stride1_forward_and_input_gradient(case):
     dx = P.conv4x4_s1_dgrad(nhwc(dy), wd, cin)
     assert dx.shape == (B, H, W, cin)
     assert relerr(nchw(dx), x.grad) < 4e-3
+    wr = w.clone().requires_grad_(True)
+    (F.conv2d(x.detach(), wr, None, stride=1, padding=1) * dy).sum().backward()
+    gw = P.conv4x4_s1_wgrad(nhwc(dy), nhwc(x.detach()))
+    assert gw.shape == (cout, cin, 4, 4)
+    assert relerr(gw.cpu(), wr.grad) < 1e-4
