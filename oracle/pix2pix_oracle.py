@@ -41,3 +41,60 @@ def instance_norm_lrelu_grads(x: Tensor, gamma: Optional[Tensor], beta: Optional
     if gamma is None:
         return dx, None, None
     return dx, (dz * xh).sum(dim=(0, 2, 3)), dz.sum(dim=(0, 2, 3))
+
+
+# ---- the two networks, from torch's own layers (builder-authored: the reference has none) -------------
+class OracleGenerator(torch.nn.Module):
+    """Same architecture and parameter names as stain2stain_amd.pix2pix.Pix2PixGenerator, on nn.Conv2d /
+    nn.ConvTranspose2d / nn.InstanceNorm2d in fp32."""
+
+    def __init__(self, in_channels=3, out_channels=3, ngf=64, num_downs=8):
+        super().__init__()
+        nn = torch.nn
+        ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]
+        self.out_channels = out_channels
+        self.downs = nn.ModuleList([nn.Conv2d(8 if i == 0 else ch[i - 1], ch[i], 4, 2, 1) for i in range(num_downs)])
+        ups = []
+        for i in range(num_downs - 1, -1, -1):
+            cin = ch[i] if i == num_downs - 1 else 2 * ch[i]
+            ups.append(nn.ConvTranspose2d(cin, 8 if i == 0 else ch[i - 1], 4, 2, 1))
+        self.ups = nn.ModuleList(ups)
+
+    def forward(self, x):
+        F = torch.nn.functional
+        n = len(self.downs)
+        x = F.pad(x, (0, 0, 0, 0, 0, 8 - x.shape[1]))
+        acts = []
+        h = F.leaky_relu(self.downs[0](x), 0.2)
+        acts.append(h)
+        for i in range(1, n - 1):
+            h = F.leaky_relu(F.instance_norm(self.downs[i](h)), 0.2)
+            acts.append(h)
+        h = torch.relu(self.downs[n - 1](h))
+        for j, up in enumerate(self.ups):
+            h = up(h)
+            if j < n - 1:
+                h = torch.relu(F.instance_norm(h))
+                h = torch.cat([torch.relu(acts[n - 2 - j]), h], 1)
+        return torch.tanh(h[:, :self.out_channels])
+
+
+class OracleDiscriminator(torch.nn.Module):
+    def __init__(self, in_channels=6, ndf=64):
+        super().__init__()
+        nn = torch.nn
+        self.c1 = nn.Conv2d(8, ndf, 4, 2, 1)
+        self.c2 = nn.Conv2d(ndf, 2 * ndf, 4, 2, 1)
+        self.c3 = nn.Conv2d(2 * ndf, 4 * ndf, 4, 2, 1)
+        self.c4 = nn.Conv2d(4 * ndf, 8 * ndf, 4, 1, 1)
+        self.c5 = nn.Conv2d(8 * ndf, 8, 4, 1, 1)
+
+    def forward(self, a, b):
+        F = torch.nn.functional
+        x = torch.cat([a, b], 1)
+        x = F.pad(x, (0, 0, 0, 0, 0, 8 - x.shape[1]))
+        h = F.leaky_relu(self.c1(x), 0.2)
+        h = F.leaky_relu(F.instance_norm(self.c2(h)), 0.2)
+        h = F.leaky_relu(F.instance_norm(self.c3(h)), 0.2)
+        h = F.leaky_relu(F.instance_norm(self.c4(h)), 0.2)
+        return self.c5(h)[:, :1]

@@ -309,3 +309,106 @@ class Conv4x4Stride1(_Layer4x4):
         if x.dim() != 4 or x.shape[1] != self.weight.shape[1] or x.shape[2] < 2 or x.shape[3] < 2:
             raise ValueError(f"expected [B, {self.weight.shape[1]}, H >= 2, W >= 2], got {tuple(x.shape)}")
         return _Conv4x4S1.apply(x, self.weight, self.bias, self._cache)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The two networks (pix2pix "unet_256"-style generator, 70x70 PatchGAN discriminator) assembled from the layers above.
+# The convolutions and the norm + activation pairs run on the HIP kernels; what is still torch glue here - the
+# activation without a norm (first / innermost layer), the ReLU of the skip tensors, the channel concatenations, tanh,
+# the losses and the optimiser - is bandwidth-bound elementwise work waiting for its kernels.
+# ------------------------------------------------------------------------------------------------------------------
+def _pad_channels(x: torch.Tensor, c: int) -> torch.Tensor:
+    return x if x.shape[1] == c else torch.nn.functional.pad(x, (0, 0, 0, 0, 0, c - x.shape[1]))
+
+
+class Pix2PixGenerator(nn.Module):
+    """U-Net generator: ``num_downs`` 4x4 stride-2 convolutions down to 1x1 (8 for 256x256 tiles) and the mirrored
+    transposed convolutions with skip connections; LeakyReLU(0.2) / InstanceNorm on the way down, ReLU / InstanceNorm
+    on the way up, tanh at the end.  Channel plan ngf * (1, 2, 4, 8, 8, ...)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, ngf: int = 64, num_downs: int = 8):
+        super().__init__()
+        if num_downs < 3:
+            raise ValueError("num_downs >= 3")
+        ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.downs = nn.ModuleList([Conv4x4Stride2(8 if i == 0 else ch[i - 1], ch[i]) for i in range(num_downs)])
+        self.down_norms = nn.ModuleList([InstanceNormLeakyReLU(ch[i], negative_slope=0.2) for i in range(1, num_downs - 1)])
+        ups, norms = [], []
+        for i in range(num_downs - 1, -1, -1):                      # innermost first
+            cin = ch[i] if i == num_downs - 1 else 2 * ch[i]
+            cout = 8 if i == 0 else ch[i - 1]
+            ups.append(ConvTranspose4x4Stride2(cin, cout))
+            if i > 0:
+                norms.append(InstanceNormLeakyReLU(cout, negative_slope=0.0))
+        self.ups, self.up_norms = nn.ModuleList(ups), nn.ModuleList(norms)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n = len(self.downs)
+        acts = []
+        h = self.downs[0](_pad_channels(x, 8))
+        h = torch.nn.functional.leaky_relu(h, 0.2)
+        acts.append(h)
+        for i in range(1, n - 1):
+            h = self.down_norms[i - 1](self.downs[i](h))
+            acts.append(h)
+        h = torch.relu(self.downs[n - 1](h))                       # innermost: no norm
+        for j, up in enumerate(self.ups):
+            h = up(h)
+            if j < n - 1:
+                h = self.up_norms[j](h)
+                h = torch.cat([torch.relu(acts[n - 2 - j]), h], 1)
+        return torch.tanh(h[:, :self.out_channels].float())
+
+
+class PatchGANDiscriminator(nn.Module):
+    """70x70 PatchGAN: C64 - C128 - C256 (stride 2) - C512 - C1 (stride 1), LeakyReLU(0.2), InstanceNorm on the three
+    middle layers; input = cat(source, target or generated) along the channels."""
+
+    def __init__(self, in_channels: int = 6, ndf: int = 64):
+        super().__init__()
+        self.c1 = Conv4x4Stride2(8, ndf)
+        self.c2, self.n2 = Conv4x4Stride2(ndf, 2 * ndf), InstanceNormLeakyReLU(2 * ndf)
+        self.c3, self.n3 = Conv4x4Stride2(2 * ndf, 4 * ndf), InstanceNormLeakyReLU(4 * ndf)
+        self.c4, self.n4 = Conv4x4Stride1(4 * ndf, 8 * ndf), InstanceNormLeakyReLU(8 * ndf)
+        self.c5 = Conv4x4Stride1(8 * ndf, 8)                        # one logit channel, padded to 8
+
+    def forward(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        h = torch.nn.functional.leaky_relu(self.c1(_pad_channels(torch.cat([a, b], 1), 8)), 0.2)
+        h = self.n2(self.c2(h))
+        h = self.n3(self.c3(h))
+        h = self.n4(self.c4(h))
+        return self.c5(h)[:, :1].float()
+
+
+def pix2pix_losses(G: nn.Module, D: nn.Module, src: torch.Tensor, tgt: torch.Tensor, lambda_l1: float = 100.0):
+    """One pix2pix evaluation: (fake, loss_D, loss_G) with the vanilla GAN objective (BCE with logits) + lambda * L1."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    fake = G(src)
+    pr, pf = D(src, tgt), D(src, fake.detach())
+    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
+    pg = D(src, fake)
+    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
+    return fake, loss_d, loss_g
+
+
+def pix2pix_step(G, D, opt_g, opt_d, src, tgt, lambda_l1: float = 100.0):
+    """The G + D optimisation step of pix2pix: discriminator update on (real, detached fake), then generator update
+    through the discriminator.  Returns (loss_D, loss_G) as tensors."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    fake = G(src)
+    opt_d.zero_grad(set_to_none=True)
+    pr, pf = D(src, tgt), D(src, fake.detach())
+    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
+    loss_d.backward()
+    opt_d.step()
+    opt_g.zero_grad(set_to_none=True)
+    for p in D.parameters():
+        p.requires_grad_(False)
+    pg = D(src, fake)
+    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
+    loss_g.backward()
+    for p in D.parameters():
+        p.requires_grad_(True)
+    opt_g.step()
+    return loss_d.detach(), loss_g.detach()

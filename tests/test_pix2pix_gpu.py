@@ -1,0 +1,73 @@
+"""pix2pix generator + PatchGAN discriminator assembled from the HIP layers, against the
+same networks built from torch's own layers in fp32 on the CPU (builder-authored oracle: the reference has no such
+model, so this row is parity-UNPINNED with respect to it).  The HIP path stores activations in bf16 (there is no fp32
+mode for these kernels yet) and InstanceNorm over the 2x2 / 4x4 maps of the inner levels amplifies that rounding, so the
+bounds are the loose ones of a bf16 pipeline: outputs in L2, losses to a few per cent, gradients by direction."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _l2(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm())
+
+
+def _pair(seed=1984):
+    from oracle import pix2pix_oracle as O
+    from stain2stain_amd.pix2pix import PatchGANDiscriminator, Pix2PixGenerator
+    torch.manual_seed(seed)
+    G, D = Pix2PixGenerator(ngf=16, num_downs=6), PatchGANDiscriminator(ndf=16)
+    Go, Do = O.OracleGenerator(ngf=16, num_downs=6), O.OracleDiscriminator(ndf=16)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    sd_g = {k: rb(v) for k, v in G.state_dict().items()}
+    sd_d = {k: rb(v) for k, v in D.state_dict().items()}
+    G.load_state_dict(sd_g); D.load_state_dict(sd_d)
+    assert set(Go.state_dict()) == set(sd_g) and set(Do.state_dict()) == set(sd_d)       # same parameter names
+    Go.load_state_dict(sd_g); Do.load_state_dict(sd_d)
+    return G.to(DEV), D.to(DEV), Go, Do
+
+
+def test_networks_match_the_torch_layer_oracle():
+    from stain2stain_amd.pix2pix import pix2pix_losses
+    G, D, Go, Do = _pair()
+    g = torch.Generator().manual_seed(7)
+    src = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    tgt = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    fake, ld, lg = pix2pix_losses(G, D, src.to(DEV), tgt.to(DEV))
+    fake_o, ld_o, lg_o = pix2pix_losses(Go, Do, src, tgt)
+    assert fake.shape == (4, 3, 64, 64) and D(src.to(DEV), tgt.to(DEV)).shape == (4, 1, 6, 6)
+    print(f"G output rel-L2 {_l2(fake.cpu(), fake_o):.3e}; loss_D {float(ld.detach()):.5f} vs {float(ld_o.detach()):.5f}; "
+          f"loss_G {float(lg.detach()):.4f} vs {float(lg_o.detach()):.4f}")
+    assert _l2(fake.cpu(), fake_o) < 3e-2                       # measured 6.5e-3
+    assert abs(float(ld) - float(ld_o)) < 2e-3 * abs(float(ld_o)) and abs(float(lg) - float(lg_o)) < 2e-3 * abs(float(lg_o))
+    (ld + lg).backward()
+    (ld_o + lg_o).backward()
+    worst = 1.0
+    pairs = list(zip(list(G.named_parameters()) + list(D.named_parameters()),
+                     list(Go.named_parameters()) + list(Do.named_parameters())))
+    scale = max(float(q.grad.norm()) for _, (_, q) in pairs)
+    for (k, p), (_, q) in pairs:
+        a, b = p.grad.float().cpu(), q.grad
+        if float(b.norm()) < 1e-4 * scale:
+            continue                      # a conv bias ahead of InstanceNorm: its gradient is analytically zero (noise)
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.95, (k, cos)                             # measured >= 0.985
+    print(f"smallest gradient cosine {worst:.4f}")
+
+
+def test_g_plus_d_step_trains():
+    """A few G + D steps on a fixed batch: finite losses, the L1-dominated generator loss goes down."""
+    from stain2stain_amd.pix2pix import pix2pix_step
+    G, D, _, _ = _pair(3)
+    og = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(9)
+    src = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1).to(DEV)
+    tgt = (src * 0.5).clone()
+    hist = [tuple(float(v) for v in pix2pix_step(G, D, og, od, src, tgt)) for _ in range(12)]
+    assert all(l == l and abs(l) < 1e4 for pair in hist for l in pair)
+    assert hist[-1][1] < hist[0][1]
