@@ -92,7 +92,7 @@ def main() -> None:
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the conv launches of every N-th timed step with HIP events for the roofline leg "
                          "(1 = every step; the marker packets cost ~10 us per bracketed launch)")
-    ap.add_argument("--mode", default="train", choices=["train", "sample"],
+    ap.add_argument("--mode", default="train", choices=["train", "sample", "pix2pix"],
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
     ap.add_argument("--euler-steps", type=int, default=50)
@@ -116,6 +116,61 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from stain2stain_amd import CFMTrainer, FlowUNet, euler_generate, ops
+
+    if args.mode == "pix2pix":
+        # Separate line: the pix2pix G + D step BASELINE.json's configs[1] is worded on - 8-level U-Net
+        # generator + 70x70 PatchGAN, batch 16, bf16 - which the reference does not contain (row a13, parity unpinned).
+        # Convolutions and norm + activation pairs on the HIP kernels; elementwise glue, losses and the two Adam
+        # optimisers are still torch.  Single GPU only (no gradient exchange wired for this path yet).
+        from stain2stain_amd.pix2pix import PatchGANDiscriminator, Pix2PixGenerator, pix2pix_step
+        if world > 1:
+            raise SystemExit("--mode pix2pix runs on one GPU")
+        torch.manual_seed(1984)
+        G, D = Pix2PixGenerator().to(dev), PatchGANDiscriminator().to(dev)
+        og = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        B = args.batch
+        g = torch.Generator().manual_seed(1984)
+        src = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
+        tgt = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
+        for _ in range(args.warmup):
+            pix2pix_step(G, D, og, od, src, tgt)
+        torch.cuda.synchronize()
+        prof, timed_steps = [], 0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sampled = i % max(1, args.event_every) == 0
+            if sampled:
+                ops.profile_start(("conv2x2_mfma", "conv2x2_wgrad_mfma", "conv4x4s1_mfma", "conv4x4s1_wgrad_mfma",
+                                   "instnorm_lrelu_fwd", "instnorm_lrelu_bwd"))
+            ld, lg = pix2pix_step(G, D, og, od, src, tgt)
+            if sampled:
+                prof += ops.profile_stop()
+                timed_steps += 1
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        agg = {}
+        for name, work, e0, e1 in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += work
+        conv = [v for k, v in agg.items() if k in ("conv2x2_mfma", "conv4x4s1_mfma")]
+        f_l, t_l, n_l = sum(v[2] for v in conv), sum(v[1] for v in conv), sum(v[0] for v in conv)
+        _emit(json.dumps({
+            "metric": f"paired {TILE}x{TILE} stain tiles/sec (pix2pix G+D optimisation step)",
+            "value": round(B * args.steps / elapsed, 3), "unit": "tiles/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"pix2pix 8-level U-Net G + 70x70 PatchGAN D, 3x{TILE}x{TILE}, batch {B}, GAN(BCE) + 100 L1, "
+                                   "two Adam(2e-4, 0.5/0.999); conv + InstanceNorm kernels in HIP, elementwise glue / "
+                                   "losses / optimiser in torch (first measurement, row a13, not in the reference)",
+                       "global_batch": B, "loss_d": round(float(ld), 5), "loss_g": round(float(lg), 4)},
+            "roofline": {"bound": "mfma", "kernel": "convkxk_dma16_kernel (forward / data-gradient / transposed launches)",
+                         "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_l // max(timed_steps, 1), "launches_timed": n_l},
+            "kernels": {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / max(timed_steps, 1), 4)}
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}))
+        return
 
     torch.manual_seed(1984)
     net = FlowUNet(3, FEATURES, 3, 256, precision=args.precision).to(dev).train()

@@ -38,3 +38,11 @@ def test_training_line_has_the_contract_keys():
 def test_sampling_line():
     d = _run("--mode", "sample", "--euler-steps", "3", "--no-cpu-baseline")
     assert d["unit"] == "tiles/s" and d["config"]["finite"] is True and d["roofline"]["achieved"] > 100
+
+
+def test_pix2pix_line():
+    """Separate line for the pix2pix G + D step (row a13 is not in the reference)."""
+    d = _run("--mode", "pix2pix")
+    assert d["unit"] == "tiles/s" and "pix2pix" in d["metric"] and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 10
+    assert d["config"]["loss_d"] == d["config"]["loss_d"] and d["config"]["loss_g"] == d["config"]["loss_g"]   # finite
