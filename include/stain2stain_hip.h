@@ -233,6 +233,11 @@ int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int
 int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout);
 int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, void* y,
                      int ldy, float* stat_part, int B, int H, int W, int Cout, int pad, void* stream);
+/* Layout change ahead of s2s_conv2x2_nhwc: xs[n][p][q][(r*2+s)*C + c] = xpad[n][2p+r][2q+s][c] with xpad = x plus a
+ * one-pixel zero border; x [B][H][W][C] (H, W even), xs [B][H/2+1][W/2+1][4C].  inverse != 0 writes x from xs (the data
+ * gradient's way back; the border cells are dropped).  bf16. */
+int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* xs, int ldxs, int inverse, int B, int H, int W,
+                            int C, void* stream);
 /* nn.Conv2d(k=4, stride=1, padding=1) of the PatchGAN's last two layers (pad = 1, input (H+1) x (W+1)) and its data
  * gradient (pad = 2, input (H-1) x (W-1), taps flipped by the packing) on the same loop with 16 taps.
  * w_packed: bf16 [ceil(cin/32)][tap kh*4+kw][Cout][32]. */

@@ -17,6 +17,7 @@
 // thread moves 16-B (bf16) / 32-B (fp32) pieces (8 channels of one pixel); partial sums are channel-major
 // ([2][B*C][blocks]) so that the finalize reads each (sample, channel) row contiguously.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -258,6 +259,84 @@ extern "C" int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const v
   else if (dtype == S2S_F32) { S2S_IN_BWD(float); }
   else return S2S_ERR_DTYPE;
 #undef S2S_IN_BWD
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// ---- space-to-depth of the zero-padded image and its inverse (row a13) -------------------------------------------
+// The 4x4 stride-2 convolution runs as a 2x2 convolution over xs[n][p][q][(r*2+s)*C + c] = xpad[n][2p+r][2q+s][c],
+// xpad = x with a one-pixel zero border (H, W even; xs is (H/2+1) x (W/2+1) x 4C).  One 16-byte piece per thread,
+// both directions; the inverse drops the border (the data gradient's border cells hold the padding's gradient).
+namespace {
+
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void s2d_pad1_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int B,
+                                                       int H, int W, int C) {
+  const int cp = C >> 3, Hs = H / 2 + 1, Ws = W / 2 + 1;
+  const long total = (long)B * H * W * cp;          // one piece of the un-padded image per thread, either direction
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int pc = (int)(i % cp);
+    long t = i / cp;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const int u = y + 1, v = x + 1;                  // position in the padded image
+    const long cell = ((long)n * Hs + (u >> 1)) * Ws + (v >> 1);
+    const int sub = ((u & 1) * 2 + (v & 1)) * C + pc * 8;
+    const long pix = ((long)n * H + y) * W + x;
+    using V = bf16x8;
+    static_assert(std::is_same<T, bf16_t>::value, "bf16 only");
+    if (INVERSE) *reinterpret_cast<V*>(dst + pix * ldd + pc * 8) = *reinterpret_cast<const V*>(src + cell * lds_ + sub);
+    else *reinterpret_cast<V*>(dst + cell * ldd + sub) = *reinterpret_cast<const V*>(src + pix * lds_ + pc * 8);
+  }
+}
+
+// the border sub-cells of xs that no image pixel maps to: row 0 (r = 0), row Hs-1 (r = 1), column 0 (s = 0), column Ws-1 (s = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_border_zero_kernel(T* __restrict__ dst, int ldd, int B, int H, int W, int C) {
+  const int cp = C >> 3, Hs = H / 2 + 1, Ws = W / 2 + 1;
+  const int per_img = 2 * Ws + 2 * Hs;               // border cells visited per image (corners twice: harmless)
+  const long total = (long)B * per_img * 2 * cp;     // x the two sub-positions along the border, x pieces
+  using V = bf16x8;
+  V z;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int pc = (int)(i % cp);
+    long t = i / cp;
+    const int o = (int)(t % 2); t /= 2;              // the free sub-index along the border
+    const int b = (int)(t % per_img);
+    const int n = (int)(t / per_img);
+    int p, q, r, s;
+    if (b < Ws) { p = 0; q = b; r = 0; s = o; }
+    else if (b < 2 * Ws) { p = Hs - 1; q = b - Ws; r = 1; s = o; }
+    else if (b < 2 * Ws + Hs) { p = b - 2 * Ws; q = 0; r = o; s = 0; }
+    else { p = b - 2 * Ws - Hs; q = Ws - 1; r = o; s = 1; }
+    *reinterpret_cast<V*>(dst + (((long)n * Hs + p) * Ws + q) * ldd + (r * 2 + s) * C + pc * 8) = z;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* xs, int ldxs, int inverse, int B, int H,
+                                       int W, int C, void* stream) {
+  if (!x || !xs) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H % 2) || (W % 2) || (C % 8) || (ldx % 8) || (ldxs % 8)) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)B * H * W * (C / 8);
+  long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (inverse) {       // x = image-shaped destination, xs = source
+    hipLaunchKernelGGL((s2d_pad1_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)xs, ldxs,
+                       (bf16_t*)const_cast<void*>(x), ldx, B, H, W, C);
+  } else {
+    const long bt = (long)B * (2 * (W / 2 + 1) + 2 * (H / 2 + 1)) * 2 * (C / 8);
+    hipLaunchKernelGGL(s2d_border_zero_kernel<bf16_t>, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, s, (bf16_t*)xs,
+                       ldxs, B, H, W, C);
+    hipLaunchKernelGGL((s2d_pad1_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       (bf16_t*)xs, ldxs, B, H, W, C);
+  }
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

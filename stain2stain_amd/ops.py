@@ -706,3 +706,24 @@ def conv4x4s1_wgrad(dy: torch.Tensor, x: torch.Tensor, grad16: torch.Tensor, acc
     rc = _L().s2s_conv4x4s1_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), _f32(grad16), int(accumulate),
                                        B, H, W, _stream())
     _native.check(rc, "conv4x4s1_wgrad")
+
+
+def space_to_depth_pad1(x: torch.Tensor) -> torch.Tensor:
+    """xs[n,p,q,(r*2+s)*C+c] = xpad[n,2p+r,2q+s,c] (one-pixel zero border): NHWC bf16 [B,H,W,C] -> [B,H/2+1,W/2+1,4C]."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    xs = torch.empty((B, H // 2 + 1, W // 2 + 1, 4 * C), dtype=x.dtype, device=x.device)
+    rc = _L().s2s_space_to_depth_pad1(_dt(x), px, ldx, xs.data_ptr(), 4 * C, 0, B, H, W, C, _stream())
+    _native.check(rc, "space_to_depth_pad1")
+    return xs
+
+
+def depth_to_space_unpad1(xs: torch.Tensor) -> torch.Tensor:
+    """Inverse of space_to_depth_pad1 (the border cells are dropped): [B,H/2+1,W/2+1,4C] -> [B,H,W,C]."""
+    B, Hs, Ws, C4 = xs.shape
+    H, W, C = 2 * (Hs - 1), 2 * (Ws - 1), C4 // 4
+    pxs, ldxs = _nhwc(xs)
+    x = torch.empty((B, H, W, C), dtype=xs.dtype, device=xs.device)
+    rc = _L().s2s_space_to_depth_pad1(_dt(xs), x.data_ptr(), C, pxs, ldxs, 1, B, H, W, C, _stream())
+    _native.check(rc, "depth_to_space_unpad1")
+    return x

@@ -74,13 +74,13 @@ class InstanceNormLeakyReLU(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# 4x4 stride-2 convolution / transposed convolution on the 2x2-tap MFMA kernel (forward and data gradient; the weight
-# gradient kernel is not built yet).  The layout changes below (space-to-depth of the padded image and its inverse, the
-# weight packing) are plain torch copies for now: they are bandwidth-bound re-orderings that belong in the epilogue of
-# the producing norm kernel.
+# 4x4 stride-2 convolution / transposed convolution on the 2x2-tap MFMA kernels (forward, data and weight
+# gradients).  The space-to-depth of the padded image and its inverse are one-pass HIP kernels
+# (ops.space_to_depth_pad1 / depth_to_space_unpad1; they belong in the apply pass of the producing norm kernel
+# eventually); the weight packing is still a handful of torch copies per step.
 # ------------------------------------------------------------------------------------------------------------------
-def space_to_depth_pad1(x: torch.Tensor) -> torch.Tensor:
-    """NHWC [B,H,W,C] (H, W even) -> [B,H/2+1,W/2+1,4C]: out[p,q,(r*2+s)*C+c] = xpad[2p+r, 2q+s, c], xpad = x with a
+def space_to_depth_pad1_torch(x: torch.Tensor) -> torch.Tensor:
+    """(torch restatement of ops.space_to_depth_pad1, kept for the tests) NHWC [B,H,W,C] (H, W even) -> [B,H/2+1,W/2+1,4C]: out[p,q,(r*2+s)*C+c] = xpad[2p+r, 2q+s, c], xpad = x with a
     one-pixel zero border."""
     B, H, W, C = x.shape
     if H % 2 or W % 2:
@@ -90,8 +90,8 @@ def space_to_depth_pad1(x: torch.Tensor) -> torch.Tensor:
     return xp.reshape(B, H // 2 + 1, W // 2 + 1, 4 * C)
 
 
-def depth_to_space_unpad1(xs: torch.Tensor) -> torch.Tensor:
-    """Inverse of space_to_depth_pad1 (drops the border)."""
+def depth_to_space_unpad1_torch(xs: torch.Tensor) -> torch.Tensor:
+    """Inverse of space_to_depth_pad1_torch (drops the border)."""
     B, Hs, Ws, C4 = xs.shape
     C = C4 // 4
     x = xs.view(B, Hs, Ws, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * Hs, 2 * Ws, C)
@@ -121,7 +121,9 @@ def pack_conv4x4_s2(w: torch.Tensor):
 
 def conv4x4_s2(x: torch.Tensor, w_fwd: torch.Tensor, bias, cout: int) -> torch.Tensor:
     """nn.Conv2d(k=4, stride=2, padding=1) on an NHWC bf16 tensor [B,H,W,Cin] -> [B,H/2,W/2,cout]."""
-    return ops.conv2x2(space_to_depth_pad1(x), w_fwd, bias, cout, 0)
+    if x.shape[1] % 2 or x.shape[2] % 2:
+        raise ValueError("conv4x4_s2: even spatial size expected")
+    return ops.conv2x2(ops.space_to_depth_pad1(x), w_fwd, bias, cout, 0)
 
 
 def conv4x4_s2_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int, bias=None) -> torch.Tensor:
@@ -129,7 +131,7 @@ def conv4x4_s2_dgrad(dy: torch.Tensor, w_dgrad: torch.Tensor, cin: int, bias=Non
     NHWC [B,H/2,W/2,Cout] -> [B,H,W,cin].  ``bias`` ([cin]) is the transposed convolution's bias: replicated over the
     four sub-pixel positions it is added by the kernel's epilogue."""
     b4 = None if bias is None else bias.float().repeat(4).contiguous()
-    return depth_to_space_unpad1(ops.conv2x2(dy, w_dgrad, b4, 4 * cin, 1))
+    return ops.depth_to_space_unpad1(ops.conv2x2(dy, w_dgrad, b4, 4 * cin, 1))
 
 
 def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
@@ -138,7 +140,7 @@ def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = Non
     view permutation of that small tensor."""
     cout, cin = dy.shape[3], x.shape[3]
     g2 = torch.empty((4, cout, 4 * cin), dtype=torch.float32, device=dy.device)
-    ops.conv2x2_wgrad(dy, space_to_depth_pad1(x), g2)
+    ops.conv2x2_wgrad(dy, ops.space_to_depth_pad1(x), g2)
     # g2[(a,b)][o][(r,s,c)] -> w[o][c][2a+r][2b+s]
     g = g2.view(2, 2, cout, 2, 2, cin).permute(2, 5, 0, 3, 1, 4).reshape(cout, cin, 4, 4)
     if grad is None:

@@ -25,13 +25,21 @@ def rb(a):
 
 
 def test_space_to_depth_round_trip():
-    from stain2stain_amd import pix2pix as P
-    x = torch.arange(2 * 6 * 8 * 8, dtype=torch.float32, device=DEV).view(2, 6, 8, 8).to(BF)
-    xs = P.space_to_depth_pad1(x)
-    assert xs.shape == (2, 4, 5, 32)
-    assert torch.equal(P.depth_to_space_unpad1(xs), x)
+    from stain2stain_amd import ops, pix2pix as P
+    for shape in [(2, 6, 8, 8), (1, 2, 2, 16), (3, 14, 4, 40)]:
+        B, H, W, C = shape
+        x = (torch.arange(B * H * W * C, dtype=torch.float32, device=DEV).view(shape) % 251 - 125).to(BF)
+        ref = P.space_to_depth_pad1_torch(x)
+        xs = ops.space_to_depth_pad1(x)
+        assert xs.shape == (B, H // 2 + 1, W // 2 + 1, 4 * C) and torch.equal(xs, ref)
+        assert torch.equal(ops.depth_to_space_unpad1(xs), x) and torch.equal(P.depth_to_space_unpad1_torch(ref), x)
+    x = (torch.arange(2 * 6 * 8 * 8, dtype=torch.float32, device=DEV).view(2, 6, 8, 8) % 251).to(BF)
+    xs = ops.space_to_depth_pad1(x)
     assert torch.equal(xs[:, 1, 1, 3 * 8:], x[:, 2, 2, :])          # (r,s) = (1,1) of cell (1,1) is xpad[3,3] = x[2,2]
     assert float(xs[:, 0, :, :16].abs().max()) == 0.0                 # r = 0 of the first cell row is the zero border
+    # a channel slice of a wider buffer as the source (pixel stride != C)
+    wide = torch.zeros(2, 6, 8, 24, device=DEV, dtype=BF); wide[..., 8:16] = x
+    assert torch.equal(ops.space_to_depth_pad1(wide[..., 8:16]), xs)
 
 
 CASES = [  # B, H, W, Cin, Cout
