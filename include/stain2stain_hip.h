@@ -238,6 +238,10 @@ int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_p
  * gradient's way back; the border cells are dropped).  bf16. */
 int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* xs, int ldxs, int inverse, int B, int H, int W,
                             int C, void* stream);
+/* fp32 master weight [Cout][Cin][4][4] of a 4x4 layer -> its two bf16 MFMA operands: wf (forward,
+ * [ceil(K/32)][taps][Cout][32]) and wd (data gradient / transposed form, [ceil(Cout/32)][taps][K][32], taps flipped);
+ * stride 2: taps = 4, K = 4*Cin (space-to-depth channel order); stride 1: taps = 16, K = Cin. */
+int s2s_pack_conv4x4(const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride, void* stream);
 /* nn.Conv2d(k=4, stride=1, padding=1) of the PatchGAN's last two layers (pad = 1, input (H+1) x (W+1)) and its data
  * gradient (pad = 2, input (H-1) x (W-1), taps flipped by the packing) on the same loop with 16 taps.
  * w_packed: bf16 [ceil(cin/32)][tap kh*4+kw][Cout][32]. */

@@ -340,3 +340,58 @@ extern "C" int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* 
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
+
+// ---- weight packing for the 4x4 layers (row a13) -----------------------------------------------------------------
+// fp32 master w[Cout][Cin][4][4] -> the two bf16 MFMA operands of s2s_conv2x2_nhwc (stride 2: taps (a,b), k =
+// (r*2+s)*Cin + c, w[o][c][2a+r][2b+s]) or s2s_conv4x4s1_nhwc (stride 1: taps (kh,kw), k = c):
+//   wf[ceil(K/32)][taps][Cout][32]            forward operand
+//   wd[ceil(Cout/32)][taps][K][32]            data-gradient operand: taps flipped, k and o exchanged
+// One element per thread; the 64-byte (o, c) blocks of the master are re-read from L2 by the threads that need
+// their other taps.
+namespace {
+
+__device__ __forceinline__ float w4x4_at(const float* __restrict__ w, int Cin, int o, int k, int tap, int stride2) {
+  int c, kh, kw;
+  if (stride2) { const int rs = k / Cin; c = k - rs * Cin; kh = 2 * (tap >> 1) + (rs >> 1); kw = 2 * (tap & 1) + (rs & 1); }
+  else { c = k; kh = tap >> 2; kw = tap & 3; }
+  return w[(((long)o * Cin + c) * 4 + kh) * 4 + kw];
+}
+
+__global__ __launch_bounds__(256) void pack4x4_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd,
+                                                      int Cout, int Cin, int stride2) {
+  const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
+  const long nf = (long)((K + 31) / 32) * taps * Cout * 32, nd = (long)((Cout + 31) / 32) * taps * K * 32;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += (long)gridDim.x * 256) {
+    if (e < nf) {
+      const int kk = (int)(e & 31);
+      long t = e >> 5;
+      const int o = (int)(t % Cout); t /= Cout;
+      const int tap = (int)(t % taps);
+      const int k = (int)(t / taps) * 32 + kk;
+      wf[e] = (bf16_t)(k < K ? w4x4_at(w, Cin, o, k, tap, stride2) : 0.f);
+    } else {
+      const long d = e - nf;
+      const int oo = (int)(d & 31);
+      long t = d >> 5;
+      const int k = (int)(t % K); t /= K;
+      const int tapf = (int)(t % taps);
+      const int o = (int)(t / taps) * 32 + oo;
+      wd[d] = (bf16_t)(o < Cout ? w4x4_at(w, Cin, o, k, taps - 1 - tapf, stride2) : 0.f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int s2s_pack_conv4x4(const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride, void* stream) {
+  if (!w_oihw || !wf || !wd) return S2S_ERR_NULL;
+  if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2)) return S2S_ERR_SHAPE;
+  const int taps = stride == 2 ? 4 : 16, K = stride == 2 ? 4 * Cin : Cin;
+  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+  long nb = (n + 255) / 256;
+  if (nb > 65535) nb = 65535;
+  hipLaunchKernelGGL(pack4x4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)wf,
+                     (bf16_t*)wd, Cout, Cin, stride == 2 ? 1 : 0);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

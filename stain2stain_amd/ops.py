@@ -727,3 +727,14 @@ def depth_to_space_unpad1(xs: torch.Tensor) -> torch.Tensor:
     rc = _L().s2s_space_to_depth_pad1(_dt(xs), x.data_ptr(), C, pxs, ldxs, 1, B, H, W, C, _stream())
     _native.check(rc, "depth_to_space_unpad1")
     return x
+
+
+def pack_conv4x4(w: torch.Tensor, stride: int):
+    """fp32 master [Cout,Cin,4,4] -> (forward operand, data-gradient operand) in bf16 for the 4x4 stride-1 / -2 kernels."""
+    cout, cin = w.shape[:2]
+    taps, K = (4, 4 * cin) if stride == 2 else (16, cin)
+    wf = torch.empty(((K + 31) // 32, taps, cout, 32), dtype=torch.bfloat16, device=w.device)
+    wd = torch.empty(((cout + 31) // 32, taps, K, 32), dtype=torch.bfloat16, device=w.device)
+    rc = _L().s2s_pack_conv4x4(_f32(w.detach().contiguous()), wf.data_ptr(), wd.data_ptr(), cout, cin, stride, _stream())
+    _native.check(rc, "pack_conv4x4")
+    return wf, wd

@@ -77,7 +77,7 @@ class InstanceNormLeakyReLU(nn.Module):
 # 4x4 stride-2 convolution / transposed convolution on the 2x2-tap MFMA kernels (forward, data and weight
 # gradients).  The space-to-depth of the padded image and its inverse are one-pass HIP kernels
 # (ops.space_to_depth_pad1 / depth_to_space_unpad1; they belong in the apply pass of the producing norm kernel
-# eventually); the weight packing is still a handful of torch copies per step.
+# eventually), and so is the weight packing (ops.pack_conv4x4).
 # ------------------------------------------------------------------------------------------------------------------
 def space_to_depth_pad1_torch(x: torch.Tensor) -> torch.Tensor:
     """(torch restatement of ops.space_to_depth_pad1, kept for the tests) NHWC [B,H,W,C] (H, W even) -> [B,H/2+1,W/2+1,4C]: out[p,q,(r*2+s)*C+c] = xpad[2p+r, 2q+s, c], xpad = x with a
@@ -107,8 +107,8 @@ def _chunks32(m: torch.Tensor) -> torch.Tensor:
     return m.view(rows, taps, kp // 32, 32).permute(2, 1, 0, 3).contiguous().to(torch.bfloat16)
 
 
-def pack_conv4x4_s2(w: torch.Tensor):
-    """nn.Conv2d(k=4, s=2, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv2x2_nhwc.
+def pack_conv4x4_s2_torch(w: torch.Tensor):
+    """(torch restatement of ops.pack_conv4x4(w, 2), kept for the tests) nn.Conv2d(k=4, s=2, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv2x2_nhwc.
     Forward: tap (a,b), k = (r*2+s)*Cin + c  <-  w[o, c, 2a+r, 2b+s].  Data gradient: the same with the taps flipped and
     the roles of k and o exchanged."""
     Cout, Cin = w.shape[:2]
@@ -117,6 +117,16 @@ def pack_conv4x4_s2(w: torch.Tensor):
     fwd = _chunks32(w2)
     wd = w2.flip(1).permute(2, 1, 0).contiguous()                        # k, (1-a,1-b), o
     return fwd, _chunks32(wd)
+
+
+def pack_conv4x4_s2(w: torch.Tensor):
+    """nn.Conv2d(k=4, s=2, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv2x2_nhwc."""
+    return ops.pack_conv4x4(w, 2)
+
+
+def pack_conv4x4_s1(w: torch.Tensor):
+    """nn.Conv2d(k=4, s=1, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv4x4s1_nhwc."""
+    return ops.pack_conv4x4(w, 1)
 
 
 def conv4x4_s2(x: torch.Tensor, w_fwd: torch.Tensor, bias, cout: int) -> torch.Tensor:
@@ -153,8 +163,8 @@ def conv4x4_s2_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor = Non
 
 
 
-def pack_conv4x4_s1(w: torch.Tensor):
-    """nn.Conv2d(k=4, s=1, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv4x4s1_nhwc:
+def pack_conv4x4_s1_torch(w: torch.Tensor):
+    """(torch restatement of ops.pack_conv4x4(w, 1), kept for the tests) nn.Conv2d(k=4, s=1, p=1) weight [Cout,Cin,4,4] -> (forward operand, data-gradient operand) of s2s_conv4x4s1_nhwc:
     [chunk][tap kh*4+kw][rows][32] with rows = Cout, k = Cin forward and rows = Cin, k = Cout, taps flipped backward."""
     Cout, Cin = w.shape[:2]
     wf = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, 16, Cin)                    # o, (kh,kw), c

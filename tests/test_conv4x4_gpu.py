@@ -184,3 +184,15 @@ def test_conv4x4_stride1_forward_and_input_gradient(case):
     gw = P.conv4x4_s1_wgrad(nhwc(dy), nhwc(x.detach()))
     assert gw.shape == (cout, cin, 4, 4)
     assert relerr(gw.cpu(), wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(64, 8), (40, 24), (136, 72), (8, 512)])
+def test_weight_packing_kernel_equals_the_torch_restatement(shape):
+    from stain2stain_amd import ops, pix2pix as P
+    cout, cin = shape
+    w = torch.randn(cout, cin, 4, 4, generator=torch.Generator().manual_seed(cout + cin)).to(DEV)
+    for stride, ref in ((2, P.pack_conv4x4_s2_torch), (1, P.pack_conv4x4_s1_torch)):
+        wf, wd = ops.pack_conv4x4(w, stride)
+        rf, rd = ref(w)
+        assert wf.shape == rf.shape and wd.shape == rd.shape
+        assert torch.equal(wf, rf) and torch.equal(wd, rd)
