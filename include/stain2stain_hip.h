@@ -238,6 +238,11 @@ int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_p
  * gradient's way back; the border cells are dropped).  bf16. */
 int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* xs, int ldxs, int inverse, int B, int H, int W,
                             int C, void* stream);
+/* out[c] (+)= sum over the npix pixels of an NHWC tensor (bias gradient of the 4x4 layers); work:
+ * float[2*C*s2s_channel_sum_blocks()]. */
+int s2s_channel_sum_blocks(long npix, int C);
+int s2s_channel_sum(int dtype, const void* x, int ldx, float* work, float* out, long npix, int C, int accumulate,
+                    void* stream);
 /* fp32 master weight [Cout][Cin][4][4] of a 4x4 layer -> its two bf16 MFMA operands: wf (forward,
  * [ceil(K/32)][taps][Cout][32]) and wd (data gradient / transposed form, [ceil(Cout/32)][taps][K][32], taps flipped);
  * stride 2: taps = 4, K = 4*Cin (space-to-depth channel order); stride 1: taps = 16, K = Cin. */

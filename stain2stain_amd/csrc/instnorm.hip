@@ -395,3 +395,44 @@ extern "C" int s2s_pack_conv4x4(const float* w_oihw, void* wf, void* wd, int Cou
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
+
+// ---- per-channel sum over every pixel of an NHWC tensor (conv-bias gradients of the a13 layers) --------------------
+// out[c] (+)= sum over [npix] of x[.][c]: the (sum, sum^2) reduction above with the whole batch as one sample, and a
+// finalize that keeps the sum.
+namespace {
+
+__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out,
+                                                                   int accumulate) {
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= C) return;
+  double a, b;
+  in_row_sums(part, C, i, nblk, threadIdx.x & 63, a, b);
+  if ((threadIdx.x & 63) == 0) out[i] = accumulate ? out[i] + (float)a : (float)a;
+}
+
+}  // namespace
+
+extern "C" int s2s_channel_sum_blocks(long npix, int C) {
+  if (npix <= 0 || npix >= (1L << 31) || C <= 0 || (C % 8)) return S2S_ERR_SHAPE;
+  return in_blocks(1, 1, (int)npix, C);
+}
+
+extern "C" int s2s_channel_sum(int dtype, const void* x, int ldx, float* work, float* out, long npix, int C,
+                               int accumulate, void* stream) {
+  if (!x || !work || !out) return S2S_ERR_NULL;
+  if (npix <= 0 || npix >= (1L << 31) || C <= 0 || (C % 8) || (ldx % 8)) return S2S_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = in_blocks(1, 1, (int)npix, C);
+  const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, 1);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL((in_reduce_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)nullptr,
+                       0, (const float*)nullptr, work, 1, (int)npix, C, 0.f);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL((in_reduce_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, ldx, (const float*)nullptr, 0,
+                       (const float*)nullptr, work, 1, (int)npix, C, 0.f);
+  else return S2S_ERR_DTYPE;
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, work, nb, C, out,
+                     accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}

@@ -738,3 +738,17 @@ def pack_conv4x4(w: torch.Tensor, stride: int):
     rc = _L().s2s_pack_conv4x4(_f32(w.detach().contiguous()), wf.data_ptr(), wd.data_ptr(), cout, cin, stride, _stream())
     _native.check(rc, "pack_conv4x4")
     return wf, wd
+
+
+def channel_sum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [C] = sum over every pixel of every sample of an NHWC (bf16 / fp32) tensor."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    npix = B * H * W
+    nb = _L().s2s_channel_sum_blocks(npix, C)
+    _native.check(min(nb, 0), "channel_sum_blocks")
+    work = torch.empty(2 * C * nb, dtype=torch.float32, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    rc = _L().s2s_channel_sum(_dt(x), px, ldx, _f32(work), _f32(out), npix, C, 0, _stream())
+    _native.check(rc, "channel_sum")
+    return out

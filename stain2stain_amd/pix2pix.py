@@ -227,7 +227,7 @@ class _Conv4x4S2(torch.autograd.Function):
         g = _to_nhwc_bf16(gy)
         dx = conv4x4_s2_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
         dw = conv4x4_s2_wgrad(g, xs)
-        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        db = ops.channel_sum(g) if ctx.has_bias else None
         return dx, dw, db, None
 
 
@@ -247,7 +247,7 @@ class _ConvT4x4S2(torch.autograd.Function):
         g = _to_nhwc_bf16(gy)                           # [B, 2H, 2W, Cout]: the "input" of the equivalent convolution
         dx = conv4x4_s2(g, ctx.wf, None, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
         dw = conv4x4_s2_wgrad(xs, g)                    # [O = Cin, C = Cout, 4, 4] = nn.ConvTranspose2d's layout
-        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        db = ops.channel_sum(g) if ctx.has_bias else None
         return dx, dw, db, None
 
 
@@ -305,7 +305,7 @@ class _Conv4x4S1(torch.autograd.Function):
         g = _to_nhwc_bf16(gy)
         dx = conv4x4_s1_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
         dw = conv4x4_s1_wgrad(g, xs)
-        db = g.float().sum((0, 1, 2)) if ctx.has_bias else None
+        db = ops.channel_sum(g) if ctx.has_bias else None
         return dx, dw, db, None
 
 

@@ -196,3 +196,14 @@ def test_weight_packing_kernel_equals_the_torch_restatement(shape):
         rf, rd = ref(w)
         assert wf.shape == rf.shape and wd.shape == rd.shape
         assert torch.equal(wf, rf) and torch.equal(wd, rd)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 24), (16, 64, 64, 128), (3, 1, 1, 8)])
+def test_channel_sum(shape):
+    from stain2stain_amd import ops
+    x = (torch.randn(*shape, generator=torch.Generator().manual_seed(5)) * 2).to(DEV, BF)
+    wide = torch.zeros(*shape[:3], shape[3] + 8, device=DEV, dtype=BF); wide[..., 8:] = x
+    ref = x.double().sum((0, 1, 2)).float()
+    assert relerr(ops.channel_sum(x), ref) < 1e-5
+    if shape[1] * shape[2] > 1:                    # a pixel stride is only expressible with more than one pixel per sample
+        assert relerr(ops.channel_sum(wide[..., 8:]), ref) < 1e-5
