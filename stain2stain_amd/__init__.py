@@ -11,11 +11,13 @@ from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowM
                             MultiTaskFlowMatchingModule, ROICharbonnierFlowMatchingModule,
                             ROIWeightedFlowMatchingModule, dopri5_generate, euler_generate)
 from . import checkpoint
-from .pix2pix import Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU
+from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU,
+                      PatchGANDiscriminator, Pix2PixGenerator, pix2pix_step)
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
            "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate",
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
-           "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2"]
+           "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",
+           "Pix2PixGenerator", "PatchGANDiscriminator", "pix2pix_step"]

@@ -42,7 +42,8 @@ def test_networks_match_the_torch_layer_oracle():
     print(f"G output rel-L2 {_l2(fake.cpu(), fake_o):.3e}; loss_D {float(ld.detach()):.5f} vs {float(ld_o.detach()):.5f}; "
           f"loss_G {float(lg.detach()):.4f} vs {float(lg_o.detach()):.4f}")
     assert _l2(fake.cpu(), fake_o) < 3e-2                       # measured 6.5e-3
-    assert abs(float(ld) - float(ld_o)) < 2e-3 * abs(float(ld_o)) and abs(float(lg) - float(lg_o)) < 2e-3 * abs(float(lg_o))
+    ldf, lgf, ldo, lgo = (float(v.detach()) for v in (ld, lg, ld_o, lg_o))
+    assert abs(ldf - ldo) < 2e-3 * abs(ldo) and abs(lgf - lgo) < 2e-3 * abs(lgo)
     (ld + lg).backward()
     (ld_o + lg_o).backward()
     worst = 1.0
