@@ -72,3 +72,34 @@ def test_g_plus_d_step_trains():
     hist = [tuple(float(v) for v in pix2pix_step(G, D, og, od, src, tgt)) for _ in range(12)]
     assert all(l == l and abs(l) < 1e4 for pair in hist for l in pair)
     assert hist[-1][1] < hist[0][1]
+
+
+def test_headline_networks_forward_against_the_oracle():
+    """The bench configuration's networks (8-level generator with ngf = 64, PatchGAN with ndf = 64) on 256x256 tiles,
+    batch 2, forward only, against the torch-layer oracle on the CPU: generator output and discriminator logits in L2."""
+    import os
+    from oracle import pix2pix_oracle as O
+    from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator
+    torch.manual_seed(1984)
+    G, D = Pix2PixGenerator(), PatchGANDiscriminator()
+    rb = lambda t: t.to(torch.bfloat16).float()
+    sd_g, sd_d = {k: rb(v) for k, v in G.state_dict().items()}, {k: rb(v) for k, v in D.state_dict().items()}
+    G.load_state_dict(sd_g); D.load_state_dict(sd_d)
+    Go, Do = O.OracleGenerator(), O.OracleDiscriminator()
+    Go.load_state_dict(sd_g); Do.load_state_dict(sd_d)
+    g = torch.Generator().manual_seed(11)
+    src = rb(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1)
+    tgt = rb(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1)
+    G, D = G.to(DEV), D.to(DEV)
+    with torch.no_grad():
+        fake = G(src.to(DEV)).cpu()
+        logits = D(src.to(DEV), tgt.to(DEV)).cpu()
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(16, os.cpu_count() or 8))
+        try:
+            fake_o, logits_o = Go(src), Do(src, tgt)
+        finally:
+            torch.set_num_threads(threads)
+    assert fake.shape == (2, 3, 256, 256) and logits.shape == (2, 1, 30, 30)
+    print(f"headline G output rel-L2 {_l2(fake, fake_o):.3e}, D logits rel-L2 {_l2(logits, logits_o):.3e}")
+    assert _l2(fake, fake_o) < 3e-2 and _l2(logits, logits_o) < 3e-2      # measured 7.0e-3 / 6.0e-3
