@@ -44,3 +44,17 @@ json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
 json.dump(out, open("profiles/hbm_traffic_current.json", "w"), indent=1)
 for k, v in out.items():
     print(f"{k:55s} {v['hbm_bytes_per_launch_corrected']/1e6:9.1f} MB/launch over {v['launches_sampled']} launches")
+
+# HBM rate per kernel from the counters: corrected bytes per launch / average launch time of the kernel-stats pass
+rates = {}
+stats = list(csv.DictReader(open(f"{src}/stats/k_kernel_stats.csv")))
+for label, needle in groups.items():
+    if label not in out:
+        continue
+    tot = sum(float(r["TotalDurationNs"]) for r in stats if needle in r["Name"])
+    n = sum(int(r["Calls"]) for r in stats if needle in r["Name"])
+    if n:
+        rates[label] = {"hbm_bytes_per_launch_corrected": out[label]["hbm_bytes_per_launch_corrected"],
+                        "avg_launch_us": round(tot / n / 1e3, 2),
+                        "hbm_gb_per_s_from_counters": round(out[label]["hbm_bytes_per_launch_corrected"] / (tot / n), 1)}
+json.dump(rates, open(f"profiles/{tag}_hbm_rates.json", "w"), indent=1)
