@@ -9,14 +9,15 @@ from .components import (ClassConditionalFlowUNet, FlowMatchingDecoder, FlowUNet
 from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowMatcher,
                             ConditionalFlowMatchingModule, MaskConditionedFlowMatchingModule,
                             MultiTaskFlowMatchingModule, ROICharbonnierFlowMatchingModule,
-                            ROIWeightedFlowMatchingModule, dopri5_generate, euler_generate)
+                            ROIWeightedFlowMatchingModule, SolverConfig, dopri5_generate, dopri5_integrate,
+                            euler_generate, euler_integrate)
 from . import checkpoint
 from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU,
                       PatchGANDiscriminator, Pix2PixGenerator, pix2pix_step)
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
-           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate",
+           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate", "euler_integrate", "dopri5_integrate", "SolverConfig",
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",

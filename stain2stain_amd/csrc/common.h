@@ -76,3 +76,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is a property of the (kernel, device) pair, so a
+// process that drives several GPUs has to set it on each of them: `done` is the caller's per-kernel bit mask of the
+// devices already served (a benign race: setting the attribute twice is harmless).
+static inline int s2s_allow_dyn_lds(const void* kern, int bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return S2S_ERR_LAUNCH;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && ((__atomic_load_n(done, __ATOMIC_RELAXED) >> dev) & 1ull)) return S2S_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return S2S_ERR_LAUNCH;
+  if (tracked) __atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELAXED);
+  return S2S_OK;
+}

@@ -892,12 +892,8 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   auto kern = conv3x3_dma16_kernel<TH, TW, BN, WM, WN, NS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -1072,12 +1068,8 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -1098,12 +1090,8 @@ int launch_dma(Conv3x3Args& a, hipStream_t s) {
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   auto kern = conv3x3_dma_kernel<TH, TW, BN, WM, WN, NS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -1124,12 +1112,8 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   auto kern = conv3x3_mfma_kernel<T, TH, TW, BN, WM, WN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -1265,12 +1249,8 @@ int launch_stem(Conv3x3Args& a, const float* x, const float* w, int Cin, hipStre
   a.tilesY = cdiv(a.H, 16);
   a.tilesX = cdiv(a.W, 16);
   auto kern = stem_mfma_kernel<T, BN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, x, w, Cin);
   S2S_LAUNCH_CHECK();
@@ -1396,9 +1376,11 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   if (!x0 || !w_packed || !y) return S2S_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
   if ((c0 % 8) || (c1 % 8) || (ld0 % 8) || (ld1 % 8) || (c1 > 0 && !x1)) return S2S_ERR_SHAPE;
+  // the epilogue stores whole 16-byte pieces (8 bf16 / 4 fp32 channels) guarded by `n < Cout` only
+  if ((Cout % 8) || (ldy % 8) || ldy < Cout) return S2S_ERR_SHAPE;
   if ((ep_scale == nullptr) != (ep_shift == nullptr)) return S2S_ERR_NULL;
-  const uintptr_t al = dtype == S2S_BF16 ? 15 : 15;
-  if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al)) return S2S_ERR_ALIGN;
+  const uintptr_t al = 15;
+  if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift;

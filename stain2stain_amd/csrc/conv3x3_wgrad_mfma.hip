@@ -437,12 +437,8 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   a.ntiles = a.B * a.tilesY * a.tilesX;
   if (a.S > a.ntiles) return S2S_ERR_SHAPE;
   auto kern = conv3x3_wgrad_kernel<T, TH, TW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -458,12 +454,8 @@ int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
   a.ntiles = a.B * a.tilesY * a.tilesX;
   if (a.S > a.ntiles) return S2S_ERR_SHAPE;
   auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * (NT == 9 ? 1 : 3));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
@@ -858,12 +850,8 @@ extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   constexpr int XROWS = ((TH + 1) * (TW + 1) + 31) / 32 * 32;
   constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   auto kern = conv2x2_wgrad_dma_kernel<TH, TW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(cin, 64), cdiv(Cout, 64), a.S);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   const long n = 4L * Cout * cin;
@@ -908,12 +896,8 @@ extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int
   constexpr int XROWS = (TH * (TW + KS - 1) + 31) / 32 * 32;
   constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   auto kern = convkxk_wgrad_rows_kernel<TH, TW, KS, 1>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return S2S_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(cin, 64), cdiv(Cout, 64), a.S * KS);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   const long n = 16L * Cout * cin;

@@ -599,13 +599,8 @@ extern "C" int s2s_stem_conv3x3_wgrad(int dtype, const void* dy, int lddy, const
                        H, W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else if (dtype == S2S_F32) {
     const int lds = 3 * (2 * 256 * 64 + 256 * 64) + 3 * 324 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<float>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return S2S_ERR_LAUNCH;
-      attr_done = true;
-    }
+    static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+    if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(stem_wgrad_kernel<float>), lds, &attr_devs)) return rc;
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, lddy, x_nchw, part, B, H,
                        W, Cin, Cout, cdiv(H, 16), cdiv(W, 16));
   } else return S2S_ERR_DTYPE;

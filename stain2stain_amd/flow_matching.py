@@ -60,21 +60,46 @@ class _MSE(torch.autograd.Function):
         return dv * gloss, None
 
 
-@torch.no_grad()
-def euler_generate(net: torch.nn.Module, source_img: torch.Tensor, num_steps: int = 50) -> torch.Tensor:
-    """x(0) = source, x <- x + v(t_k, x)/n at t_k = k/n, network in eval mode; returns x(1)."""
-    was_training = net.training
-    net.eval()
+class _eval_mode:
+    """``module.eval()`` for the duration of a sampling loop, previous mode restored even when the loop raises.  Only
+    the module handed in is touched: wrappers around a LightningModule are plain callables, never ``nn.Module``s that
+    would register it as a child and flip its mode behind its back."""
+
+    def __init__(self, net):
+        self.net = net if isinstance(net, torch.nn.Module) else None
+
+    def __enter__(self):
+        if self.net is not None:
+            self.was = self.net.training
+            self.net.eval()
+
+    def __exit__(self, *exc):
+        if self.net is not None:
+            self.net.train(self.was)
+        return False
+
+
+def _prep_source(source_img: torch.Tensor) -> torch.Tensor:
     if source_img.dim() == 3:
         source_img = source_img.unsqueeze(0)
-    x = source_img.detach().float().contiguous().clone()
+    return source_img.detach().float().contiguous().clone()
+
+
+@torch.no_grad()
+def euler_integrate(f, x: torch.Tensor, num_steps: int) -> torch.Tensor:
+    """x <- x + f(t_k, x)/n at t_k = k/n for a callable ``f(t[B], x)``; ``x`` is advanced in place and returned."""
     dt = 1.0 / num_steps
     for k in range(num_steps):
         t = torch.full((x.shape[0],), k * dt, device=x.device, dtype=torch.float32)
-        v = net(t, x)
-        ops.axpy_(x, v.contiguous(), dt)
-    net.train(was_training)
+        ops.axpy_(x, f(t, x).contiguous(), dt)
     return x
+
+
+@torch.no_grad()
+def euler_generate(net, source_img: torch.Tensor, num_steps: int = 50) -> torch.Tensor:
+    """x(0) = source, x <- x + v(t_k, x)/n at t_k = k/n, network in eval mode (its mode is restored); returns x(1)."""
+    with _eval_mode(net):
+        return euler_integrate(net, _prep_source(source_img), num_steps)
 
 
 # Dormand-Prince 5(4): nodes, stage matrix (row 7 = the 5th-order weights, first-same-as-last) and error weights
@@ -90,9 +115,17 @@ _DP_E = (-71 / 57600, 0.0, 71 / 16695, -71 / 1920, 17253 / 339200, -22 / 525, 1 
 
 
 @torch.no_grad()
-def dopri5_generate(net: torch.nn.Module, source_img: torch.Tensor, atol: float = 1e-4, rtol: float = 1e-4,
-                    max_steps: int = 1000, return_stats: bool = False):
-    """Adaptive sampler: x(1) of dx/dt = v(t, x), x(0) = source, eval-mode network, by the Dormand-Prince 5(4) pair.
+def dopri5_generate(net, source_img: torch.Tensor, atol: float = 1e-4, rtol: float = 1e-4, max_steps: int = 1000,
+                    return_stats: bool = False):
+    """``dopri5_integrate`` on a network put in eval mode for the solve (mode restored, also when it raises)."""
+    with _eval_mode(net):
+        return dopri5_integrate(net, _prep_source(source_img), atol, rtol, max_steps, return_stats)
+
+
+@torch.no_grad()
+def dopri5_integrate(net, y: torch.Tensor, atol: float = 1e-4, rtol: float = 1e-4, max_steps: int = 1000,
+                     return_stats: bool = False):
+    """Adaptive sampler for a callable ``net(t[B], x)``: x(1) of dx/dt = v(t, x), x(0) = source, eval-mode network, by the Dormand-Prince 5(4) pair.
 
     The reference integrates with torchdyn's ``NeuralODE(solver="dopri5", atol=1e-4, rtol=1e-4)``
     (conditional_flow_matching.py:157-170); torchdyn is absent, so the step-size control here is the textbook one
@@ -100,11 +133,6 @@ def dopri5_generate(net: torch.nn.Module, source_img: torch.Tensor, atol: float 
     after a rejection, Hairer's initial-step heuristic) -- parity with torchdyn's controller is unpinned, the
     solution agrees with any dopri5 to the tolerances.  Stage combinations and the error norm run in HIP
     (``s2s_axpy``, ``s2s_ode_error_norm``); one host read of the error norm per attempted step."""
-    was_training = net.training
-    net.eval()
-    if source_img.dim() == 3:
-        source_img = source_img.unsqueeze(0)
-    y = source_img.detach().float().contiguous().clone()
     B = y.shape[0]
 
     def f(t, x):
@@ -160,8 +188,46 @@ def dopri5_generate(net: torch.nn.Module, source_img: torch.Tensor, atol: float 
             n_rej += 1
     else:
         raise RuntimeError("dopri5_generate: max_steps reached before t = 1")
-    net.train(was_training)
     return (y, {"accepted": n_acc, "rejected": n_rej}) if return_stats else y
+
+
+class SolverConfig:
+    """Stand-in for the reference's ``solver:`` entry (a partial of torchdyn's ``NeuralODE``,
+    configs/model/conditional_flow_matching.yaml:32-38): the attributes ``generate`` reads from it."""
+
+    def __init__(self, solver: str = "dopri5", sensitivity: str = "adjoint", atol: float = 1e-4, rtol: float = 1e-4):
+        self.solver, self.sensitivity, self.atol, self.rtol = solver, sensitivity, atol, rtol
+
+
+def _solver_setting(solver, name: str, default):
+    """``solver.<name>`` as the reference reads it (conditional_flow_matching.py:158-163: attribute if present, else
+    the default); the keyword of a ``functools.partial`` -- what Hydra's ``_partial_: true`` builds -- is honoured too."""
+    if hasattr(solver, name):
+        return getattr(solver, name)
+    kw = getattr(solver, "keywords", None)
+    if isinstance(kw, dict) and name in kw:
+        return kw[name]
+    return default
+
+
+def _solve(module, f, source_img: torch.Tensor, num_steps: int, method: Optional[str], atol: Optional[float],
+           rtol: Optional[float]) -> torch.Tensor:
+    """The ODE solve shared by every ``generate``: like the reference it refuses to run without a solver, puts the
+    module in eval mode and LEAVES it there (``self.eval()``, conditional_flow_matching.py:147-150), integrates with
+    the solver's method / tolerances (dopri5, 1e-4 when it names none) and returns the end point x(1).  ``method``
+    overrides the solver's choice: "euler" is the ``num_steps`` fixed-step solve of BASELINE.json configs[3]."""
+    if module.solver is None:
+        raise ValueError("Solver is not initialized. Cannot perform inference.")
+    module.eval()
+    method = method or _solver_setting(module.solver, "solver", "dopri5")
+    atol = _solver_setting(module.solver, "atol", 1e-4) if atol is None else atol
+    rtol = _solver_setting(module.solver, "rtol", 1e-4) if rtol is None else rtol
+    x = _prep_source(source_img)
+    if method == "dopri5":
+        return dopri5_integrate(f, x, atol, rtol)
+    if method == "euler":
+        return euler_integrate(f, x, num_steps)
+    raise ValueError(f"solver method must be 'dopri5' or 'euler', got {method!r}")
 
 
 class ConditionalFlowMatchingModule(_Base):
@@ -205,16 +271,13 @@ class ConditionalFlowMatchingModule(_Base):
         return {"optimizer": optimizer}
 
     @torch.no_grad()
-    def generate(self, source_img: torch.Tensor, num_steps: int = 100, method: str = "euler", atol: float = 1e-4,
-                 rtol: float = 1e-4) -> torch.Tensor:
-        """``method="euler"``: ``num_steps`` fixed steps (BASELINE.json configs[3]); ``method="dopri5"``: the adaptive
-        Dormand-Prince solve the reference runs through torchdyn (atol = rtol = 1e-4, :157-170), where ``num_steps``
-        only defined the output grid and plays no role for the end point returned here."""
-        if method == "dopri5":
-            return dopri5_generate(self.net, source_img, atol, rtol)
-        if method != "euler":
-            raise ValueError(f"method must be 'euler' or 'dopri5', got {method!r}")
-        return euler_generate(self.net, source_img, num_steps)
+    def generate(self, source_img: torch.Tensor, num_steps: int = 100, method: Optional[str] = None,
+                 atol: Optional[float] = None, rtol: Optional[float] = None) -> torch.Tensor:
+        """x(1) of dx/dt = net(t, x), x(0) = source (conditional_flow_matching.py:133-170): the solver's method --
+        adaptive dopri5 at atol = rtol = 1e-4 unless ``self.solver`` says otherwise; ``num_steps`` only defined the
+        reference's output grid and plays no role for the end point -- or, with ``method="euler"``, ``num_steps``
+        fixed Euler steps.  Raises without a solver and leaves the module in eval mode, as the reference does."""
+        return _solve(self, self.net, source_img, num_steps, method, atol, rtol)
 
 
 class _WeightedMSE(torch.autograd.Function):
@@ -284,20 +347,12 @@ class MaskConditionedFlowMatchingModule(ConditionalFlowMatchingModule):
         return loss
 
     @torch.no_grad()
-    def generate(self, source_img: torch.Tensor, mask: torch.Tensor, num_steps: int = 100) -> torch.Tensor:
+    def generate(self, source_img: torch.Tensor, mask: torch.Tensor, num_steps: int = 100,
+                 method: Optional[str] = None, atol: Optional[float] = None, rtol: Optional[float] = None) -> torch.Tensor:
+        """conditional_flow_matching_conditional_mask.py:143-199: the mask rides along as a constant fourth channel."""
         if source_img.dim() == 3:
             source_img, mask = source_img.unsqueeze(0), mask.unsqueeze(0)
-        outer = self
-
-        class _Net(torch.nn.Module):
-            def forward(s, t, x):
-                return outer.forward(t, x, mask)
-
-        was = self.net.training
-        self.net.eval()
-        out = euler_generate(_Net(), source_img, num_steps)
-        self.net.train(was)
-        return out
+        return _solve(self, lambda t, x: self.forward(t, x, mask), source_img, num_steps, method, atol, rtol)
 
 
 class ClassConditionalFlowMatchingModule(ConditionalFlowMatchingModule):
@@ -313,24 +368,19 @@ class ClassConditionalFlowMatchingModule(ConditionalFlowMatchingModule):
         return _MSE.apply(self.forward(t, xt, label.long()), ut)
 
     @torch.no_grad()
-    def generate(self, source_img: torch.Tensor, target_class, num_steps: int = 100) -> torch.Tensor:
+    def generate(self, source_img: torch.Tensor, target_class, num_steps: int = 100, method: Optional[str] = None,
+                 atol: Optional[float] = None, rtol: Optional[float] = None) -> torch.Tensor:
+        """class_conditional_flow_matching.py:130-190: ``target_class`` an int or a [B] tensor."""
         if source_img.dim() == 3:
             source_img = source_img.unsqueeze(0)
         B, dev = source_img.shape[0], source_img.device
         y = (torch.tensor([target_class] * B, device=dev) if isinstance(target_class, int)
              else target_class.to(dev))
-        outer = self
 
-        class _Net(torch.nn.Module):
-            def forward(s, t, x):
-                yy = y.expand(x.shape[0]) if y.dim() == 0 else y[:x.shape[0]]
-                return outer.net(t, x, y=yy)
+        def f(t, x):
+            return self.net(t, x, y=(y.expand(x.shape[0]) if y.dim() == 0 else y[:x.shape[0]]))
 
-        was = self.net.training
-        self.net.eval()
-        out = euler_generate(_Net(), source_img, num_steps)
-        self.net.train(was)
-        return out
+        return _solve(self, f, source_img, num_steps, method, atol, rtol)
 
 
 class _SegLoss(torch.autograd.Function):
@@ -433,8 +483,13 @@ class MultiTaskFlowMatchingModule(_Base):
         return {"optimizer": optimizer}
 
     @torch.no_grad()
-    def generate(self, source_img: torch.Tensor, num_steps: int = 100):
-        """(generated image by fixed-step Euler, mask probabilities) like the reference's generate (:419-484)."""
+    def generate(self, source_img: torch.Tensor, num_steps: int = 100, method: Optional[str] = None,
+                 atol: Optional[float] = None, rtol: Optional[float] = None):
+        """(generated image, mask probabilities / class map) like the reference's generate (:419-484): the module goes
+        to eval mode and stays there, the mask head runs once on the source, the flow is integrated with the solver's
+        method (dopri5 at 1e-4 by default; ``method="euler"`` = ``num_steps`` fixed steps)."""
+        if self.solver is None:
+            raise ValueError("Solver is not initialized. Cannot perform inference.")
         self.eval()
         if source_img.dim() == 3:
             source_img = source_img.unsqueeze(0)
@@ -443,13 +498,4 @@ class MultiTaskFlowMatchingModule(_Base):
             pred_mask = torch.argmax(torch.softmax(logits, dim=1), dim=1, keepdim=True)
         else:
             pred_mask = torch.sigmoid(logits)
-
-        class _Net(torch.nn.Module):
-            def __init__(s, outer):
-                super().__init__()
-                s.outer = outer
-
-            def forward(s, t, x):
-                return s.outer.forward_flow(t, x)
-
-        return euler_generate(_Net(self), source_img, num_steps), pred_mask
+        return _solve(self, self.forward_flow, source_img, num_steps, method, atol, rtol), pred_mask

@@ -226,8 +226,8 @@ class _Conv4x4S2(torch.autograd.Function):
         (xs,) = ctx.saved_tensors
         g = _to_nhwc_bf16(gy)
         dx = conv4x4_s2_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
-        dw = conv4x4_s2_wgrad(g, xs)
-        db = ops.channel_sum(g) if ctx.has_bias else None
+        dw = conv4x4_s2_wgrad(g, xs) if ctx.needs_input_grad[1] else None      # frozen D in the generator pass
+        db = ops.channel_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 
@@ -246,8 +246,8 @@ class _ConvT4x4S2(torch.autograd.Function):
         (xs,) = ctx.saved_tensors
         g = _to_nhwc_bf16(gy)                           # [B, 2H, 2W, Cout]: the "input" of the equivalent convolution
         dx = conv4x4_s2(g, ctx.wf, None, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
-        dw = conv4x4_s2_wgrad(xs, g)                    # [O = Cin, C = Cout, 4, 4] = nn.ConvTranspose2d's layout
-        db = ops.channel_sum(g) if ctx.has_bias else None
+        dw = conv4x4_s2_wgrad(xs, g) if ctx.needs_input_grad[1] else None    # [O = Cin, C = Cout, 4, 4] = nn.ConvTranspose2d's layout
+        db = ops.channel_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 
@@ -304,8 +304,8 @@ class _Conv4x4S1(torch.autograd.Function):
         (xs,) = ctx.saved_tensors
         g = _to_nhwc_bf16(gy)
         dx = conv4x4_s1_dgrad(g, ctx.wd, ctx.cin).permute(0, 3, 1, 2).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
-        dw = conv4x4_s1_wgrad(g, xs)
-        db = ops.channel_sum(g) if ctx.has_bias else None
+        dw = conv4x4_s1_wgrad(g, xs) if ctx.needs_input_grad[1] else None
+        db = ops.channel_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 

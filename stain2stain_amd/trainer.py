@@ -66,6 +66,16 @@ class FusedAdamHandle(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:      # every backward overwrites the flat gradient buffer
         pass
 
+    # The handle's own parameter list is the one flat buffer, which carries no per-parameter state: a checkpoint
+    # written from the inherited state_dict() would silently drop exp_avg / exp_avg_sq / step.  Lightning and user
+    # code checkpoint optimisers through these two methods, so they speak torch.optim.Adam's layout over
+    # net.parameters() (what the reference's checkpoint["optimizer_states"][0] holds).
+    def state_dict(self):
+        return self._trainer.optimizer_state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        self._trainer.load_optimizer_state_dict(state_dict)
+
 
 class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,

@@ -298,3 +298,42 @@ def test_dopri5_sampler_matches_scipy_rk45_on_the_oracle():
     assert stats["accepted"] + stats["rejected"] == (sol.nfev - 2) // 6     # same number of attempted steps
     fine = euler_generate(net, x.to(DEV), 400).cpu()
     assert float((got.cpu() - fine).abs().max()) < 2e-2 * float(fine.abs().max())
+
+
+def test_optimizer_handle_checkpoints_the_adam_state():
+    """``trainer.optimizer.state_dict()`` (what Lightning / user code checkpoints) must carry exp_avg,
+    exp_avg_sq and step in torch.optim.Adam's layout over net.parameters(); a resume through
+    ``optimizer.load_state_dict`` continues bit for bit like the uninterrupted run."""
+    from stain2stain_amd import CFMTrainer, FlowUNet
+    g = torch.Generator().manual_seed(21)
+    x0 = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    x1 = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    ts = [torch.rand(4, generator=g).to(DEV) for _ in range(4)]
+
+    def fresh():
+        torch.manual_seed(5)
+        net = FlowUNet(3, [16, 32], 3, 32, precision="fp32").to(DEV).train()
+        return net, CFMTrainer(net, lr=1e-3, weight_decay=1e-5)
+
+    net_a, tr_a = fresh()
+    for t in ts[:2]:
+        tr_a.step(x0, x1, t)
+    sd_opt = tr_a.optimizer.state_dict()
+    n_par = len(list(net_a.parameters()))
+    assert len(sd_opt["state"]) == n_par and sd_opt["param_groups"][0]["params"] == list(range(n_par))
+    st0 = sd_opt["state"][0]
+    assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 2.0
+    assert float(st0["exp_avg"].abs().max()) > 0
+    torch.optim.Adam(net_a.parameters()).load_state_dict(sd_opt)          # torch's own Adam accepts the layout
+    sd_net = {k: v.clone() for k, v in net_a.state_dict().items()}
+    for t in ts[2:]:
+        tr_a.step(x0, x1, t)
+    net_b, tr_b = fresh()
+    net_b.load_state_dict(sd_net)
+    tr_b._repack()
+    tr_b.optimizer.load_state_dict(sd_opt)
+    assert tr_b.step_count == 2
+    for t in ts[2:]:
+        tr_b.step(x0, x1, t)
+    for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert torch.equal(a, b), k

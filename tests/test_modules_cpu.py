@@ -73,3 +73,74 @@ def test_product_path_refuses_host_tensors():
     net = FlowUNet(3, [16, 32], 3, 32)
     with pytest.raises(RuntimeError):
         net(torch.rand(2), torch.rand(2, 3, 16, 16))
+
+
+def test_generate_follows_the_reference_mode_and_solver_rules(monkeypatch):
+    """Host logic of generate() (reference conditional_flow_matching.py:133-170, ..._multitask.py:419-484) with the two
+    HIP ops of the integrators replaced by their torch one-liners (no GPU here): no solver -> ValueError; the module is
+    put in eval mode and left there; the solver's method and tolerances are read from attributes or from the keywords
+    of a functools.partial (what Hydra's ``_partial_: true`` builds); sampling helpers restore the mode they found,
+    also when the network raises."""
+    from stain2stain_amd import (ConditionalFlowMatchingModule, MultiTaskFlowMatchingModule, SolverConfig, euler_generate,
+                                 flow_matching, ops)
+    monkeypatch.setattr(ops, "axpy_", lambda x, y, a: x.add_(y, alpha=a))
+    monkeypatch.setattr(ops, "ode_error_norm", lambda e, a, b, atol, rtol: torch.sqrt(torch.mean(
+        (e / (atol + rtol * torch.maximum(a.abs(), b.abs()))) ** 2)).reshape(1))
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm2d(3)
+            self.calls = 0
+
+        def forward(self, t, x, **kw):
+            self.calls += 1
+            assert not self.training and t.shape == (x.shape[0],)
+            return -x
+
+    x = torch.rand(2, 3, 4, 4)
+    m = ConditionalFlowMatchingModule(Net())
+    with pytest.raises(ValueError, match="Solver is not initialized"):
+        m.generate(x)
+    m = ConditionalFlowMatchingModule(Net(), solver=SolverConfig()).train()
+    out = m.generate(x)                                              # dopri5: x(1) = x(0) / e
+    assert not m.training and not m.net.training and not m.net.bn.training
+    assert float((out - x * torch.exp(torch.tensor(-1.0))).abs().max()) < 1e-3
+    n_adaptive = m.net.calls
+    m.net.calls = 0
+    out = m.generate(x, num_steps=10, method="euler")
+    assert m.net.calls == 10 and float((out - x * 0.9 ** 10).abs().max()) < 1e-6
+    # a partial (Hydra) carries its settings in .keywords; attribute-less objects fall back to dopri5 / 1e-4
+    part = functools.partial(SolverConfig, solver="euler")
+    assert flow_matching._solver_setting(part, "solver", "dopri5") == "euler"
+    assert flow_matching._solver_setting(object(), "atol", 1e-4) == 1e-4
+    m2 = ConditionalFlowMatchingModule(Net(), solver=part)
+    m2.generate(x, num_steps=3)
+    assert m2.net.calls == 3 and n_adaptive > 6
+    # helper functions: mode restored, also on failure
+    net = Net().train()
+    euler_generate(net, x, 2)
+    assert net.training
+
+    class Boom(Net):
+        def forward(self, t, x):
+            raise RuntimeError("boom")
+
+    b = Boom().train()
+    with pytest.raises(RuntimeError, match="boom"):
+        euler_generate(b, x, 2)
+    assert b.training
+    # multitask: generate() must not leave the module in train mode (ADVICE r1) -- it stays in eval like the reference
+    class Enc(torch.nn.Module):
+        def forward(self, x):
+            return x, []
+
+    class Dec(torch.nn.Module):
+        def forward(self, b, skips, temb=None):
+            return -b if temb is not None else b[:, :1]
+
+    mt = MultiTaskFlowMatchingModule(Enc(), Dec(), Dec(), solver=SolverConfig("euler"), time_emb_dim=8)
+    monkeypatch.setattr(type(mt.time_embedding), "forward", lambda self, t: t[:, None].expand(-1, 8))
+    mt.train()
+    img, pm = mt.generate(x, num_steps=4)
+    assert not mt.training and img.shape == x.shape and pm.shape == (2, 1, 4, 4)

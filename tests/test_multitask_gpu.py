@@ -25,7 +25,8 @@ def build(G, precision):
     enc.load_state_dict(sub(G, "init/encoder."))
     fdec.load_state_dict(sub(G, "init/flow_decoder."))
     sdec.load_state_dict(sub(G, "init/seg_decoder."))
-    return MultiTaskFlowMatchingModule(enc, fdec, sdec, time_emb_dim=32).to(DEV).train()
+    from stain2stain_amd import SolverConfig
+    return MultiTaskFlowMatchingModule(enc, fdec, sdec, time_emb_dim=32, solver=SolverConfig()).to(DEV).train()
 
 
 @pytest.mark.parametrize("n", [1, 777, 4 * 64 * 64, 16 * 256 * 256])
@@ -104,9 +105,22 @@ def test_model_step_and_generate(G):
         vals[prec] = float(total.detach())
     assert abs(vals["bf16"] - vals["fp32"]) < 2e-2 * abs(vals["fp32"])
     mod = build(G, "fp32")
-    img, pm = mod.generate(x0[:2], num_steps=3)
+    # generate(): eval mode during and after the call (the reference's self.eval(), :437), BatchNorm running
+    # statistics untouched, the solver's adaptive dopri5 by default and fixed-step Euler on request
+    mod.train()
+    before = {k: v.clone() for k, v in mod.state_dict().items() if "running_" in k or "num_batches" in k}
+    img, pm = mod.generate(x0[:2], num_steps=3, method="euler")
     assert img.shape == (2, 3, 64, 64) and pm.shape == (2, 1, 64, 64)
     assert float(pm.min()) >= 0 and float(pm.max()) <= 1
+    assert not mod.training and not any(m.training for m in mod.modules())
+    img2, _ = mod.generate(x0[:2])                                   # dopri5, atol = rtol = 1e-4
+    fine, _ = mod.generate(x0[:2], num_steps=200, method="euler")
+    assert relerr(img2, fine) < 2e-2 and not mod.training
+    after = mod.state_dict()
+    assert before and all(torch.equal(after[k], v) for k, v in before.items())
+    mod.solver = None
+    with pytest.raises(ValueError, match="Solver is not initialized"):
+        mod.generate(x0[:2])
 
 
 # ---- multiclass form ------------------------------------------------------------------------------------------
@@ -161,7 +175,9 @@ def test_multiclass_step_matches_golden_fp32(GM):
     enc.load_state_dict(sub(G, "init/encoder."))
     fdec.load_state_dict(sub(G, "init/flow_decoder."))
     sdec.load_state_dict(sub(G, "init/seg_decoder."))
-    mod = MultiTaskFlowMatchingModule(enc, fdec, sdec, time_emb_dim=32, num_classes=5).to(DEV).train()
+    from stain2stain_amd import SolverConfig
+    mod = MultiTaskFlowMatchingModule(enc, fdec, sdec, time_emb_dim=32, num_classes=5,
+                                      solver=SolverConfig("euler")).to(DEV).train()
     x0, x1, t, mask = (G[k].to(DEV) for k in ("x0", "x1", "t", "mask"))
     _, xt, ut = mod.flow_matcher.sample_location_and_conditional_flow(x0, x1, t)
     flow = torch.mean((mod.forward_flow(t, xt) - ut) ** 2)

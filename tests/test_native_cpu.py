@@ -26,6 +26,13 @@ def test_host_side_validation_returns_status_codes_without_a_gpu():
     lib = _native.lib()
     # null pointers / bad shapes are rejected before any launch
     assert lib.s2s_conv3x3_nhwc(0, None, 8, 8, None, 8, 0, None, None, None, 8, None, None, None, 0, 1, 4, 4, 8, None) == -5
+    # output side of the conv ABI: Cout / ldy multiples of 8, ldy >= Cout, 16-byte aligned y -- the
+    # epilogue stores whole 16-byte pieces, so anything else must be refused, not written out of bounds
+    ok = ctypes.c_void_p(4096)
+    conv = lambda cout, ldy, y: lib.s2s_conv3x3_nhwc(0, ok, 8, 8, None, 8, 0, ok, None, y, ldy, None, None, None, 0,
+                                                      1, 4, 4, cout, None)
+    assert conv(12, 16, ok) == -1 and conv(8, 12, ok) == -1 and conv(16, 8, ok) == -1
+    assert conv(8, 8, ctypes.c_void_p(4096 + 8)) == -2
     assert lib.s2s_conv3x3_stat_blocks(0, 16, 256, 256, 64) == 16 * 32 * 8
     assert lib.s2s_conv3x3_stat_blocks(1, 16, 256, 256, 64) == 16 * 64 * 8
     assert lib.s2s_conv3x3_stat_blocks(7, 1, 8, 8, 8) == -3

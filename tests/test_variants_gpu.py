@@ -84,7 +84,8 @@ def test_variant_modules_model_step(G):
     assert float(charb) > 0 and torch.isfinite(lw) and float(lc.detach()) > float(charb)
     lw.backward()
     assert all(p.grad is not None for p in net3.parameters())
-    mod = MaskConditionedFlowMatchingModule(build_net(G), mask_toggle=True)
+    from stain2stain_amd import SolverConfig
+    mod = MaskConditionedFlowMatchingModule(build_net(G), mask_toggle=True, solver=SolverConfig("euler"))
     seen = set()
     for s in range(8):                                             # torch.rand(1) < 0.5 decides, as in the reference
         torch.manual_seed(s)
@@ -95,7 +96,7 @@ def test_variant_modules_model_step(G):
         assert torch.isfinite(loss)
     assert seen == {True, False}
     img = mod.generate(x0[:2], mask[:2], num_steps=2)
-    assert img.shape == (2, 3, 64, 64) and mod.net.training
+    assert img.shape == (2, 3, 64, 64) and not mod.net.training      # eval mode stays, as in the reference
 
 
 def test_class_conditional_net_matches_oracle_fp32(G):
@@ -124,7 +125,8 @@ def test_class_conditional_net_matches_oracle_fp32(G):
     else:
         pytest.fail("no well-conditioned initialisation found")
     net = net.to(DEV).train()
-    mod = ClassConditionalFlowMatchingModule(net)
+    from stain2stain_amd import SolverConfig
+    mod = ClassConditionalFlowMatchingModule(net, solver=SolverConfig("euler"))
     _, xt, ut = mod.flow_matcher.sample_location_and_conditional_flow(x0.to(DEV), x1.to(DEV), t.to(DEV))
     v = mod.forward(t.to(DEV), xt, y.to(DEV))
     loss = torch.mean((v - ut) ** 2)
