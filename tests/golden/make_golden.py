@@ -53,35 +53,70 @@ def flow(enc, dec, temb, t, x):
 
 
 def make_step_fixture(name, feats, hw, batch, n_steps, tdim):
-    torch.manual_seed(SEED)
-    enc = SharedEncoder(3, list(feats))
-    dec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
-    temb = TimeEmbedding(tdim)
-    g = torch.Generator().manual_seed(SEED)
-    out = {}
-    for k, v in full_state(enc, dec).items():
-        out["init/" + k] = npy(v)
-    params = named_params(enc, dec)
-    opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=1e-4, weight_decay=1e-5)
-    enc.train(); dec.train()
-    for s in range(n_steps):
-        x0 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
-        x1 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
-        t = torch.rand(batch, generator=g)
-        tb = t.view(-1, 1, 1, 1)
-        xt = tb * x1 + (1 - tb) * x0
-        ut = x1 - x0
-        opt.zero_grad()
-        v = flow(enc, dec, temb, t, xt)
-        loss = torch.mean((v - ut) ** 2)
-        loss.backward()
-        out[f"step{s}/x0"] = npy(x0); out[f"step{s}/x1"] = npy(x1); out[f"step{s}/t"] = npy(t)
-        out[f"step{s}/v"] = npy(v); out[f"step{s}/loss"] = npy(loss)
-        for k, p in params.items():
-            out[f"step{s}/grad/" + k] = npy(p.grad)
-        opt.step()
-        for k, val in full_state(enc, dec).items():
-            out[f"step{s}/after/" + k] = npy(val)
+    """n_steps optimisation steps of the plain CFM model.  The weights are drawn under the experiments' seed (the
+    init/ entries double as the check that the build's modules initialise like the reference's); the DATA seed is
+    screened like the later fixtures': a ReLU / max-pool network has ~1e6 discrete decisions per step and on most draws
+    one pre-activation sits within rounding of zero, which moves individual gradient tensors by 2e-3 .. 2e-2 between
+    fp32 and fp64 of the reference itself.  Such a draw cannot pin anything at 1e-3, so the first data seed is kept on
+    which the reference's own gradients of EVERY step agree to 2e-4 across fp32, fp64 and fp64 with a 3e-7 input
+    jitter (the round-1 fixture was unscreened and its second step needed 3e-3)."""
+
+    def run(data_seed, dtype, jitter=0, record_all=True):
+        torch.manual_seed(SEED)
+        enc = SharedEncoder(3, list(feats))
+        dec = FlowMatchingDecoder(feats[-1], list(feats[:-1][::-1]), 3, tdim)
+        temb = TimeEmbedding(tdim)
+        g = torch.Generator().manual_seed(data_seed)
+        out = {}
+        for k, v in full_state(enc, dec).items():
+            out["init/" + k] = npy(v)
+        enc.to(dtype); dec.to(dtype)
+        params = named_params(enc, dec)
+        opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=1e-4, weight_decay=1e-5)
+        enc.train(); dec.train()
+        gj = torch.Generator().manual_seed(jitter) if jitter else None
+        for s in range(n_steps):
+            x0 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
+            x1 = torch.rand(batch, 3, hw[0], hw[1], generator=g) * 2 - 1
+            t = torch.rand(batch, generator=g)
+            out[f"step{s}/x0"] = npy(x0); out[f"step{s}/x1"] = npy(x1); out[f"step{s}/t"] = npy(t)
+            x0, x1, t = x0.to(dtype), x1.to(dtype), t.to(dtype)
+            if gj is not None:
+                x0 = x0 + 3e-7 * torch.randn(x0.shape, generator=gj, dtype=dtype)
+                x1 = x1 + 3e-7 * torch.randn(x1.shape, generator=gj, dtype=dtype)
+            tb = t.view(-1, 1, 1, 1)
+            xt = tb * x1 + (1 - tb) * x0
+            ut = x1 - x0
+            opt.zero_grad()
+            b, skips = enc(xt)
+            v = dec(b, skips, temb(t).to(dtype))
+            loss = torch.mean((v - ut) ** 2)
+            loss.backward()
+            out[f"step{s}/v"] = npy(v); out[f"step{s}/loss"] = npy(loss)
+            for k, p in params.items():
+                out[f"step{s}/grad/" + k] = npy(p.grad)
+            opt.step()
+            if record_all:
+                for k, val in full_state(enc, dec).items():
+                    out[f"step{s}/after/" + k] = npy(val)
+        return out, (enc, dec, temb, x0)
+
+    for data_seed in range(SEED, SEED + 200):
+        out, (enc, dec, temb, x0) = run(data_seed, torch.float32)
+        ref64, _ = run(data_seed, torch.float64, record_all=False)
+        worst = 0.0
+        for other in [out] + [run(data_seed, torch.float64, j, record_all=False)[0] for j in (1, 2, 3, 4)]:
+            for s in range(n_steps):
+                keys = [k for k in ref64 if k.startswith(f"step{s}/grad/")]
+                gs = max(float(np.abs(ref64[k]).max()) for k in keys)
+                worst = max(worst, max(float(np.abs(other[k] - ref64[k]).max())
+                                       / max(float(np.abs(ref64[k]).max()), 1e-3 * gs) for k in keys))
+        print(f"  {name}: data seed {data_seed}: reference gradients under fp32/fp64/jitter move by {worst:.2e}")
+        if worst < 2e-4:
+            break
+    else:
+        raise RuntimeError("no well-conditioned data seed found")
+    out["meta/data_seed"] = np.int64(data_seed)
     # eval-mode fixed-step Euler from the last source batch (BASELINE.json config 4, tiny)
     enc.eval(); dec.eval()
     n_euler = 50
@@ -457,13 +492,13 @@ def make_input_fixture():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
-    make_step_fixture("tiny_step.npz", (16, 32), (64, 64), 4, 2, 32)
-    # three levels, non-square, odd at level 1 (38 -> 19 -> 9; 9*2=18 vs 19 -> pad branch)
-    make_step_fixture("odd3_step.npz", (8, 16, 24), (38, 44), 2, 1, 16)
-    make_ops_fixture()
-    make_multitask_fixture()
-    make_multiclass_fixture()
-    make_checkpoint_fixture()
-    make_variants_fixture()
-    make_input_fixture()
+    todo = {
+        # BASELINE.json configs[0]: 64x64x3, 2-level U-Net, batch 4, fp32 CPU
+        "tiny": lambda: make_step_fixture("tiny_step.npz", (16, 32), (64, 64), 4, 2, 32),
+        # three levels, non-square, odd at level 1 (38 -> 19 -> 9; 9*2=18 vs 19 -> pad branch)
+        "odd3": lambda: make_step_fixture("odd3_step.npz", (8, 16, 24), (38, 44), 2, 1, 16),
+        "ops": make_ops_fixture, "multitask": make_multitask_fixture, "multiclass": make_multiclass_fixture,
+        "checkpoint": make_checkpoint_fixture, "variants": make_variants_fixture, "input": make_input_fixture,
+    }
+    for key in (sys.argv[1:] or list(todo)):        # python make_golden.py [tiny odd3 ...] regenerates a subset
+        todo[key]()

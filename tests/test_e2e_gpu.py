@@ -30,10 +30,8 @@ def state_of(net):
 
 
 def check_grads(got, ref, tol=TOL):
-    """tol: 1e-3 on the first step.  Later steps get 3e-3: with the golden post-step-0 parameters exactly one
-    of the 262,144 last-layer pre-activations lies within fp32 rounding of zero, and flipping that single ReLU
-    decision (which any change of summation order does, measured with scripts/debug_paths.py) moves the
-    heavily cancelling BatchNorm beta-gradient by 7e-5 and the upstream weight gradients by up to 2e-3."""
+    """1e-3 (max-norm per tensor) on every step: the fixtures' data seeds are screened for ReLU / max-pool knife
+    edges (tests/golden/make_golden.py, make_step_fixture), so no step needs a wider bound."""
     TOL = tol
     scale = max(float(v.abs().max()) for v in ref.values())
     for k, r in ref.items():
@@ -86,7 +84,7 @@ def test_autograd_modules_match_golden_fp32(name, golden_tiny, golden_odd3):
         assert relerr(loss, G[f"step{s}/loss"]) < TOL
         got = {"encoder." + k: p.grad for k, p in net.encoder.named_parameters()}
         got.update({"flow_decoder." + k: p.grad for k, p in net.flow_decoder.named_parameters()})
-        check_grads(got, sub(G, f"step{s}/grad/"), TOL if s == 0 else 3 * TOL)
+        check_grads(got, sub(G, f"step{s}/grad/"), TOL)
         opt.step()
         check_after(net, G, s, s + 1)
 
@@ -106,7 +104,7 @@ def test_fused_trainer_matches_golden_fp32(name, golden_tiny, golden_odd3):
         assert relerr(loss, G[f"step{s}/loss"]) < TOL
         got = {"encoder." + k: p.grad.clone() for k, p in net.encoder.named_parameters()}
         got.update({"flow_decoder." + k: p.grad.clone() for k, p in net.flow_decoder.named_parameters()})
-        check_grads(got, sub(G, f"step{s}/grad/"), TOL if s == 0 else 3 * TOL)
+        check_grads(got, sub(G, f"step{s}/grad/"), TOL)
         tr.optimizer_step()
         check_after(net, G, s, s + 1)
 

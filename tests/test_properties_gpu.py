@@ -80,7 +80,12 @@ def test_batchnorm_invariants_full_size_forward():
             assert float(m) < 2e-2 and float(v) < 2e-2, (lvl, float(m), float(v))
             act = lc.act.float()
             assert float(act.min()) >= 0.0
-            assert torch.equal(act > 0, (raw * lc.stats[2] + lc.stats[3]).to(torch.bfloat16).float() > 0) or True
+            # ReLU mask = sign of the normalised value: the kernel evaluates fma(raw, scale, shift) in fp32, torch's
+            # unfused multiply-add here may round differently, so a disagreement is only legal on a knife edge
+            z = raw * lc.stats[2] + lc.stats[3]
+            mism = (act > 0) != (z > 0)
+            assert float(mism.float().mean()) < 1e-5, (lvl, float(mism.float().mean()))
+            assert not bool(mism.any()) or float(z[mism].abs().max()) < 1e-5, (lvl, float(z[mism].abs().max()))
 
 
 def test_cfg5_tile_size_trains():
