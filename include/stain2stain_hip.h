@@ -263,6 +263,65 @@ int s2s_conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout);
 int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin, float* part,
                            float* grad2, int accumulate, int B, int H, int W, void* stream);
 
+/* ---- the pix2pix G + D step's remaining kernels (row a13; no reference line to replace) -------------
+ * General form of the two convolutions above, both dtypes (fp32 = three-way bf16 split, the parity mode):
+ *   ks = 2, pad 0 | 1: 4x4 stride-2 convolution on the space-to-depth image | its data gradient = transposed convolution
+ *   ks = 4, pad 1 | 2: 4x4 stride-1 convolution | its data gradient.          H, W: OUTPUT size.
+ * w_packed: [ceil(cin/32)][ks*ks][Cout][32] in the activation dtype (s2s_pack_conv4x4_t).
+ * act != 0: y = t > 0 ? t : act_slope * t on the bias-added output (the layers WITHOUT a norm: LeakyReLU(0.2) / ReLU).
+ * y2 (optional, pixel stride ldy2): a second copy max(y, 0), the ReLU'd skip tensor written into the decoder's
+ * concatenation buffer.  bias_mod (0 = Cout): the bias of output channel n is bias[n % bias_mod] -- Cout / 4 for the
+ * transposed layers, whose four sub-pixel channel groups share the layer's bias vector.  stat_part (optional): float[2][Cout][s2s_convkxk_stat_blocks()]. */
+int s2s_convkxk_stat_blocks(int dtype, int B, int H, int W, int Cout, int ks);
+int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, int bias_mod,
+                     void* y, int ldy, void* y2, int ldy2, int act, float act_slope, float* stat_part, int B, int H, int W,
+                     int Cout, int ks, int pad, void* stream);
+/* Weight gradient of the pad-0 (ks = 2) / pad-1 (ks = 4) forms: dY [B][H][W][Cout], X [B][H+1][W+1][cin].
+ * layout 0: grad[ks*ks][Cout][cin]; layout 1: nn.Conv2d's [Cout][C][4][4] (ks = 2: cin = 4 C over the space-to-depth
+ * channels; with the roles of a transposed layer's input and output gradient exchanged the same call yields
+ * nn.ConvTranspose2d's [Cin][Cout][4][4]).  part: float[s2s_convkxk_wgrad_splits()][ks*ks][Cout][cin] scratch. */
+int s2s_convkxk_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout, int ks);
+int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin, float* part,
+                           float* grad, int layout, int accumulate, int B, int H, int W, int ks, void* stream);
+/* InstanceNorm + LeakyReLU with a second output y2 = relu(z) (pixel stride ldy2, optional) and, backward, a second
+ * incoming gradient g2 (wrt y2, optional): dz = z > 0 ? g + g2 : slope * g.  Otherwise as s2s_instnorm_lrelu_fwd/bwd. */
+int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                            void* y2, int ldy2, float* work, float* stats, int B, int H, int W, int C, float eps,
+                            float slope, void* stream);
+int s2s_instnorm_lrelu_bwd2(int dtype, const void* g, int ldg, const void* g2, int ldg2, const void* x, int ldx,
+                            const float* stats, void* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                            float* work, int B, int H, int W, int C, float slope, void* stream);
+/* s2s_pack_conv4x4 with the operands in the activation dtype; the batched form re-packs every 4x4 layer of a network in
+ * one launch after the fused Adam step: desc = device long[nlayers][7] {w master, wf, wd, Cout, Cin, stride == 2, first
+ * block}, a layer occupies s2s_pack_conv4x4_blocks() blocks, total = their sum. */
+int s2s_pack_conv4x4_t(int dtype, const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride, void* stream);
+long s2s_pack_conv4x4_blocks(int Cout, int Cin, int stride);
+int s2s_pack_conv4x4_batched(int dtype, const void* desc, int nlayers, long total, void* stream);
+/* out[B][H][W][8] (pixel stride ldo) <- [a (ca channels) | b (cb channels, optional) | zeros] from NCHW fp32 images: the
+ * generator's input (source tile) and the discriminator's (source | target). */
+int s2s_p2p_pack_input(int dtype, const float* a_nchw, int ca, const float* b_nchw, int cb, void* out, int ldo, int B,
+                       int H, int W, void* stream);
+/* Generator head: fake = tanh(h[..., :C]); d_in <- [src | fake | zeros] (the discriminator's input, 8 channels);
+ * fake_nchw (optional) <- fake as NCHW fp32; l1_out[0] = mean |fake - tgt|.  work: double[s2s_p2p_tanh_l1_blocks()]. */
+int s2s_p2p_tanh_l1_blocks(int B, int H, int W);
+int s2s_p2p_tanh_l1_fwd(int dtype, const void* h, int ldh, const float* src_nchw, const float* tgt_nchw, void* d_in,
+                        int ldd, float* fake_nchw, float* l1_out, void* work, int B, int H, int W, int C, void* stream);
+/* dh[..., c] = (l1_scale * sign(fake - tgt) + gd[..., C + c]) * (1 - fake^2) for c < C, 0 on the padding channels;
+ * gd (optional) = gradient wrt the discriminator's input. */
+int s2s_p2p_tanh_l1_bwd(int dtype, const void* h, int ldh, const float* tgt_nchw, const void* gd, int ldg, float l1_scale,
+                        void* dh, int lddh, int B, int H, int W, int C, void* stream);
+/* BCEWithLogits of a PatchGAN logit map z[N][HW][ldz] (logit = channel 0): samples n < n_real against ones, the others
+ * against zeros.  out2[0] / out2[1] = the two means; dz (optional, 8 channels, pixel stride lddz)[..., 0] =
+ * w_real * (sigmoid(z) - 1) | w_fake * sigmoid(z), 0 on the padding channels. */
+int s2s_p2p_bce_logits(int dtype, const void* z, int ldz, int n_real, float w_real, float w_fake, void* dz, int lddz,
+                       float* out2, int N, int HW, void* stream);
+/* Backward of a LeakyReLU / ReLU without a norm in front, from its stored output a: dz = a > 0 ? g + g2 : slope * g
+ * (g2 optional: the gradient wrt the ReLU'd copy); dbias (optional) (+)= per-channel sum of dz.
+ * work: float[C * s2s_p2p_act_bwd_blocks()]. */
+int s2s_p2p_act_bwd_blocks(long npix, int C);
+int s2s_p2p_act_bwd(int dtype, const void* g, int ldg, const void* g2, int ldg2, const void* a, int lda, float slope,
+                    void* dz, int lddz, float* work, float* dbias, int accumulate, long npix, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowM
 from . import checkpoint
 from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU,
                       PatchGANDiscriminator, Pix2PixGenerator, pix2pix_step)
+from .pix2pix_engine import Pix2PixTrainer
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
@@ -21,4 +22,4 @@ __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeE
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",
-           "Pix2PixGenerator", "PatchGANDiscriminator", "pix2pix_step"]
+           "Pix2PixGenerator", "PatchGANDiscriminator", "pix2pix_step", "Pix2PixTrainer"]

@@ -44,6 +44,16 @@ struct Conv3x3Args {
   int ld0, c0, ld1, c1, ldy;
   int B, H, W, Cout, tilesY, tilesX, nchunk;
   int relu;
+  // activation of a layer WITHOUT a norm behind it (row a13: the pix2pix generator's outermost / innermost layers, the
+  // PatchGAN's first layer), applied to bias-added outputs when no folded affine is given: act = 1 -> t > 0 ? t :
+  // act_slope * t (LeakyReLU; slope 0 = ReLU).  y2 (optional): a second copy max(y, 0) with its own pixel stride --
+  // the ReLU'd skip tensor written straight into the decoder's concatenation buffer.
+  int act;
+  float act_slope;
+  void* y2;
+  int ldy2;
+  int bias_mod;   // bias index = channel % bias_mod (= Cout normally; Cout / 4 for the transposed 4x4 layers, whose four
+                  // sub-pixel channel groups share one bias vector)
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
 };
 
@@ -134,7 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc
         const int nl = wn * WTN + ni * 32 + r;
         const int n = n0 + nl;
         const bool nok = n < a.Cout;
-        const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+        const float bias = (nok && a.bias) ? a.bias[n % a.bias_mod] : 0.f;
         const float esc = (nok && a.ep_scale) ? a.ep_scale[n] : 1.f;
         const float esh = (nok && a.ep_shift) ? a.ep_shift[n] : 0.f;
 #pragma unroll
@@ -148,6 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc
             float t = acc[mi][ni][j] + bias;
             if (a.ep_scale) t = t * esc + esh;
             if (a.relu) t = fmaxf(t, 0.f);
+            if (a.act) t = t > 0.f ? t : a.act_slope * t;
             v[j] = t;
             if (nok && y0 + py < a.H && x0p + px < a.W) { s1[ni] += t; s2[ni] += t * t; }
           }
@@ -186,7 +197,22 @@ __device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc
       const int gy = y0 + py, gx = x0p + px, n = n0 + c * EPC;
       if (idx < PM * CPR && gy < a.H && gx < a.W && n < a.Cout) {
         const f32x4 val = *reinterpret_cast<const f32x4*>(otile + ml * RS + c * 16);
-        *reinterpret_cast<f32x4*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
+        const long opix = ((long)img * a.H + gy) * a.W + gx;
+        *reinterpret_cast<f32x4*>(yout + opix * a.ldy + n) = val;
+        if (a.y2) {
+          if constexpr (SPLIT) {
+            f32x4 r4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r4[k] = fmaxf(val[k], 0.f);
+            *reinterpret_cast<f32x4*>(static_cast<T*>(a.y2) + opix * a.ldy2 + n) = r4;
+          } else {
+            const bf16x8 v8 = __builtin_bit_cast(bf16x8, val);
+            bf16x8 r8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r8[k] = (float)v8[k] > 0.f ? v8[k] : (bf16_t)0.f;
+            *reinterpret_cast<bf16x8*>(static_cast<T*>(a.y2) + opix * a.ldy2 + n) = r8;
+          }
+        }
       }
     }
   }
@@ -216,11 +242,17 @@ __device__ __forceinline__ void conv_epilogue(const Conv3x3Args& a, f32x16 (&acc
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN>
+// KS / PAD generalise the loop to the KS x KS-tap forms of row a13 (see convkxk_dma16_kernel below for the geometry:
+// a.H / a.W are the OUTPUT size, the input is (H + KS - 1 - 2 PAD) high): this register-staged form is what the fp32
+// parity mode of those layers runs on.
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KS = 3, int PAD = 1>
 __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr bool SPLIT = std::is_same<T, float>::value;
   constexpr int NIMG = SPLIT ? 3 : 1;
-  constexpr int HW_ = TW + 2, HH_ = TH + 2, HALO = HW_ * HH_;
+  constexpr int TAPS = KS * KS;
+  constexpr int NSET = (TAPS % 3 == 0) ? 3 : 4;      // rotating weight register sets; TAPS % NSET == 0 keeps set = tap % NSET
+  static_assert(TAPS % NSET == 0, "weight register rotation");
+  constexpr int HW_ = TW + KS - 1, HH_ = TH + KS - 1, HALO = HW_ * HH_;
   constexpr int A_BYTES = HALO * ROWB, B_BYTES = BN * ROWB;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
   constexpr int A_PIECES = HALO * 4, A_IT = (A_PIECES + 255) / 256;
@@ -246,6 +278,7 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   const int y0 = ty * TH, x0p = tx * TW;
   const int n0 = blockIdx.y * BN;
   const int ctot = a.c0 + a.c1;
+  const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;      // input size (= output size for 3x3 / pad 1)
 
   // ---- per-thread staging coordinates (chunk independent) ----
   int apix[A_IT];    // pixel index into the NHWC tensor, -1 = zero fill
@@ -254,12 +287,12 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
     const int idx = tid + i * 256;
     const int px = idx >> 2, pc = idx & 3;
     const int hy = px / HW_, hx = px - hy * HW_;
-    const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
-    apix[i] = (idx < A_PIECES && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                  ? (img * a.H + gy) * a.W + gx : -1;
+    const int gy = y0 - PAD + hy, gx = x0p - PAD + hx;
+    apix[i] = (idx < A_PIECES && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+                  ? (img * Hi + gy) * Wi + gx : -1;
   }
   Piece<T> hreg[A_IT];
-  Piece<T> wreg[3][B_IT];   // three rotating sets (slab index mod 3 == tap mod 3): two taps of load latency
+  Piece<T> wreg[NSET][B_IT];   // rotating sets (slab index mod NSET == tap mod NSET): NSET - 1 taps of load latency
 
   auto load_halo = [&](int c) {
 #pragma unroll
@@ -282,7 +315,6 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
   };
   auto load_w = [&](int it, auto setc) {
     constexpr int set = decltype(setc)::value;
-    const int c = it / 9, tap = it - c * 9;
     const T* base = wp + ((long)it * a.Cout) * 32;   // slabs are packed in iteration order [chunk][tap]
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -322,28 +354,27 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
-  const int nit = a.nchunk * 9;
+  const int nit = a.nchunk * TAPS;
 
   // ---- prologue ----
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  load_w(0, I0{});
+  load_w(0, std::integral_constant<int, 0>{});
   load_halo(0);
-  store_w(0, I0{});
+  store_w(0, std::integral_constant<int, 0>{});
   store_halo(0);
-  if (nit > 1) load_w(1, I1{});
-  if (nit > 2) load_w(2, I2{});
+  static_for<NSET - 1>([&](auto k) {
+    constexpr int kk = decltype(k)::value + 1;
+    if (nit > kk) load_w(kk, std::integral_constant<int, kk>{});
+  });
   __syncthreads();
 
   for (int c = 0; c < a.nchunk; ++c) {
     if (c + 1 < a.nchunk) load_halo(c + 1);
     const char* Ahi = ldsA + (c & 1) * NIMG * A_BYTES;
-    static_for<9>([&](auto tapc) {
+    static_for<TAPS>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
-      const int it = c * 9 + tap;
+      const int it = c * TAPS + tap;
       const char* Bhi = ldsB + (it & 1) * NIMG * B_BYTES;
-      const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * ROWB;
+      const int tapoff = ((tap / KS) * HW_ + (tap % KS)) * ROWB;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[MI], bfr[NI];
@@ -383,11 +414,11 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
       }
       // slot (it+1)&1 was last read by tap it-1, which every wave left at the previous barrier
-      // slab it+1 sits in register set (tap+1)%3 (loaded two taps ago); slab it+3 goes into the set that
-      // held slab it (tap%3), whose LDS copy was written one tap ago
-      if (it + 1 < nit) store_w((it + 1) & 1, std::integral_constant<int, (tap + 1) % 3>{});
-      if (it + 3 < nit) load_w(it + 3, std::integral_constant<int, tap % 3>{});
-      if (tap == 8 && c + 1 < a.nchunk) store_halo((c + 1) & 1);
+      // slab it+1 sits in register set (tap+1)%NSET (loaded NSET-1 taps ago); slab it+NSET goes into the set that
+      // held slab it (tap%NSET), whose LDS copy was written one tap ago
+      if (it + 1 < nit) store_w((it + 1) & 1, std::integral_constant<int, (tap + 1) % NSET>{});
+      if (it + NSET < nit) load_w(it + NSET, std::integral_constant<int, tap % NSET>{});
+      if (tap == TAPS - 1 && c + 1 < a.nchunk) store_halo((c + 1) & 1);
       __syncthreads();
     });
   }
@@ -665,6 +696,8 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
             if (AFFINE) {
               t = t * esc[ni][j] + esh[ni][j];
               if (a.relu) t = fmaxf(t, 0.f);
+            } else if (a.act) {
+              t = t > 0.f ? t : a.act_slope * t;
             }
             pk[j] = (bf16_t)t;
           }
@@ -683,8 +716,14 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
       const int gy = y0 + py, gx = x0p + px, n = n0 + c * 8;
       if (full || (gy < a.H && gx < a.W && n < a.Cout)) {
         const bf16x8 val = *reinterpret_cast<const bf16x8*>(otile + ml * RS + c * 16);
-        if (!(a.dbg & 8))
-          *reinterpret_cast<bf16x8*>(yout + (((long)img * a.H + gy) * a.W + gx) * a.ldy + n) = val;
+        const long opix = ((long)img * a.H + gy) * a.W + gx;
+        if (!(a.dbg & 8)) *reinterpret_cast<bf16x8*>(yout + opix * a.ldy + n) = val;
+        if (a.y2) {
+          bf16x8 r8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) r8[k] = (float)val[k] > 0.f ? val[k] : (bf16_t)0.f;
+          *reinterpret_cast<bf16x8*>(static_cast<T*>(a.y2) + opix * a.ldy2 + n) = r8;
+        }
         if (want_stats) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -1040,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * WTN + ni * 16 + 4 * kp + j;
-      biasr[ni][j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+      biasr[ni][j] = (a.bias && n < a.Cout) ? a.bias[n % a.bias_mod] : 0.f;
     }
   {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
@@ -1098,11 +1137,11 @@ int launch_dma(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN>
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KS = 3, int PAD = 1>
 int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   constexpr bool SPLIT = std::is_same<T, float>::value;
   constexpr int NIMG = SPLIT ? 3 : 1;
-  constexpr int lds_main = 2 * NIMG * ((TH + 2) * (TW + 2) + BN) * ROWB;
+  constexpr int lds_main = 2 * NIMG * ((TH + KS - 1) * (TW + KS - 1) + BN) * ROWB;
   constexpr int RS_ = BN * (int)sizeof(T) + (SPLIT ? 16 : 64);
   constexpr int red_ = WM * 2 * BN * 4;
   constexpr int EP_ = (TH * TW * RS_ + red_ <= lds_main) ? 1 : ((TH * TW / 2) * RS_ + red_ <= lds_main ? 2 : 4);
@@ -1111,7 +1150,7 @@ int launch_cfg(Conv3x3Args& a, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
-  auto kern = conv3x3_mfma_kernel<T, TH, TW, BN, WM, WN>;
+  auto kern = conv3x3_mfma_kernel<T, TH, TW, BN, WM, WN, KS, PAD>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
@@ -1341,7 +1380,7 @@ int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, c
                           float* stat_part, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
   Conv3x3Args a;
   a.x0 = a.x1 = a.w = nullptr; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = a.ep_shift = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout;
   a.ld0 = a.c0 = a.ld1 = a.c1 = 0; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = 1; a.relu = 0; a.dbg = 0;
   a.tilesX = a.tilesY = 0;
@@ -1383,7 +1422,7 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
@@ -1393,65 +1432,87 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   return dispatch(dtype, a, s);
 }
 
-// ---- 2x2-tap convolution (row a13: 4x4 stride-2 conv / conv-transpose on the space-to-depth image) ----------------
-// Output H x W; pad 0: input (H+1) x (W+1), y[i][j] = sum_{a,b} W[a][b] x[i+a][j+b]; pad 1: input (H-1) x (W-1),
-// y[i][j] = sum_{a,b} W[a][b] x[i+a-1][j+b-1] (zero outside).  w_packed: bf16 [ceil(Cin/32)][4][Cout][32].
-extern "C" int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
-  return B * cdiv(H, 8) * cdiv(W, W > 16 ? 32 : 16);
+// ---- KS x KS-tap convolutions of row a13 -------------------------------------------------------------------------
+// Output H x W, y[i][j] = sum_{a,b < ks} W[a][b] x[i + a - pad][j + b - pad] (zero outside), input (H + ks - 1 - 2 pad):
+//   ks = 2, pad = 0: the 4x4 stride-2 pad-1 convolution, as a 2x2 "valid" convolution over the space-to-depth image of
+//                    the padded input (K = 4 taps x 4 Cin, no wasted MACs);
+//   ks = 2, pad = 1: its data gradient = the 4x4 stride-2 transposed convolution (flipped taps: see s2s_pack_conv4x4),
+//                    output in space-to-depth form with a one-cell border;
+//   ks = 4, pad = 1: the PatchGAN's 4x4 stride-1 pad-1 layers;   ks = 4, pad = 2: their data gradient.
+// w_packed: [ceil(cin/32)][ks*ks][Cout][32] in the activation dtype.  dtype bf16 runs the LDS-DMA 16x16x32 loop,
+// fp32 the register-staged three-way bf16 split (parity mode).  act / act_slope / y2 / bias_mod (0 = Cout): see
+// Conv3x3Args.
+extern "C" int s2s_convkxk_stat_blocks(int dtype, int B, int H, int W, int Cout, int ks) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ks != 2 && ks != 4)) return S2S_ERR_SHAPE;
+  if (dtype == S2S_F32) return W > 16 ? B * cdiv(H, 4) * cdiv(W, 32) : B * cdiv(H, 8) * cdiv(W, 16);
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (ks == 2) return B * cdiv(H, 8) * cdiv(W, W > 16 ? 32 : 16);
+  return W > 16 ? B * cdiv(H, 4) * cdiv(W, 32) : B * cdiv(H, 8) * cdiv(W, 16);
 }
 
-extern "C" int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
-                                void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
-                                void* stream) {
+extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
+                                int bias_mod, void* y, int ldy, void* y2, int ldy2, int act, float act_slope,
+                                float* stat_part, int B, int H, int W, int Cout, int ks, int pad, void* stream) {
   if (!x || !w_packed || !y) return S2S_ERR_NULL;
-  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;                 // throughput mode only so far
-  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8)) return S2S_ERR_SHAPE;
-  if (pad != 0 && pad != 1) return S2S_ERR_SHAPE;
-  if (pad == 1 && (H < 2 || W < 2)) return S2S_ERR_SHAPE;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return S2S_ERR_ALIGN;
-  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;     // 32-bit pixel index in the halo loader
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8) || ldy < Cout) return S2S_ERR_SHAPE;
+  if (y2 && ((ldy2 % 8) || ldy2 < Cout)) return S2S_ERR_SHAPE;
+  if (bias_mod < 0 || (bias_mod > 0 && Cout % bias_mod)) return S2S_ERR_SHAPE;
+  if (!((ks == 2 && (pad == 0 || pad == 1)) || (ks == 4 && (pad == 1 || pad == 2)))) return S2S_ERR_SHAPE;
+  if (H + ks - 1 - 2 * pad < 1 || W + ks - 1 - 2 * pad < 1) return S2S_ERR_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 3) * (W + 3) >= (1L << 31)) return S2S_ERR_SHAPE;     // 32-bit pixel index in the halo loader
   Conv3x3Args a;
   a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = a.ep_shift = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
+  a.bias_mod = bias_mod > 0 ? bias_mod : Cout;
   a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
   a.tilesX = a.tilesY = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wide = W > 16, big = Cout > 64;
-  if (pad == 0) {
-    if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0>(a, s);
-    return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0>(a, s);
+  const int form = ks * 4 + pad;        // 8: 2x2 valid, 9: 2x2 pad 1, 17: 4x4 pad 1, 18: 4x4 pad 2
+  if (dtype == S2S_F32) {
+    switch (form) {
+      case 8:  return wide ? launch_cfg<float, 4, 32, 64, 2, 2, 2, 0>(a, s) : launch_cfg<float, 8, 16, 64, 2, 2, 2, 0>(a, s);
+      case 9:  return wide ? launch_cfg<float, 4, 32, 64, 2, 2, 2, 1>(a, s) : launch_cfg<float, 8, 16, 64, 2, 2, 2, 1>(a, s);
+      case 17: return wide ? launch_cfg<float, 4, 32, 64, 2, 2, 4, 1>(a, s) : launch_cfg<float, 8, 16, 64, 2, 2, 4, 1>(a, s);
+      default: return wide ? launch_cfg<float, 4, 32, 64, 2, 2, 4, 2>(a, s) : launch_cfg<float, 8, 16, 64, 2, 2, 4, 2>(a, s);
+    }
   }
-  if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1>(a, s);
-  return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1>(a, s);
+  switch (form) {
+    case 8:
+      if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0>(a, s);
+      return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0>(a, s);
+    case 9:
+      if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1>(a, s);
+      return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1>(a, s);
+    case 17:      // 4-row tiles on wide maps: two workgroups per CU with the 7-row halo
+      if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 1>(a, s);
+      return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 1>(a, s);
+    default:
+      if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 2>(a, s);
+      return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 2>(a, s);
+  }
 }
 
-// ---- 4x4 stride-1 convolution (row a13: the PatchGAN discriminator's last two layers) -----------------------------
-// Output H x W; pad 1: nn.Conv2d(k=4, stride=1, padding=1), input (H+1) x (W+1); pad 2: its data gradient, input
-// (H-1) x (W-1), taps flipped by the packing.  w_packed: bf16 [ceil(Cin/32)][16][Cout][32].
+// the two entry points of round 1, kept for their callers: s2s_convkxk_nhwc without activation / second output
+extern "C" int s2s_conv2x2_stat_blocks(int B, int H, int W, int Cout) {
+  return s2s_convkxk_stat_blocks(S2S_BF16, B, H, W, Cout, 2);
+}
+
+extern "C" int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
+                                void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
+                                void* stream) {
+  if (pad != 0 && pad != 1) return S2S_ERR_SHAPE;
+  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, B, H, W, Cout, 2, pad,
+                          stream);
+}
+
 extern "C" int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
                                   void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
                                   void* stream) {
-  if (!x || !w_packed || !y) return S2S_ERR_NULL;
-  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
-  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8)) return S2S_ERR_SHAPE;
   if (pad != 1 && pad != 2) return S2S_ERR_SHAPE;
-  if (pad == 2 && (H < 2 || W < 2)) return S2S_ERR_SHAPE;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15)) return S2S_ERR_ALIGN;
-  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
-  Conv3x3Args a;
-  a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = a.ep_shift = nullptr;
-  a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
-  a.tilesX = a.tilesY = 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool wide = W > 16, big = Cout > 64;      // 4-row tiles on wide maps: two workgroups per CU with the 7-row halo
-  if (pad == 1) {
-    if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 1>(a, s);
-    return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 1>(a, s);
-  }
-  if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 2>(a, s);
-  return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 2>(a, s);
+  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, B, H, W, Cout, 4, pad,
+                          stream);
 }

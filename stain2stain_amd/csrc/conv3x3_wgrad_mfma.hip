@@ -743,6 +743,178 @@ __global__ __launch_bounds__(256, 2) void convkxk_wgrad_rows_kernel(WgradArgs a)
   }
 }
 
+// Register-staged form of the kernel above for either dtype (T = float: three-way bf16 split of both operands, the
+// parity mode; see conv3x3_wgrad_kernel).  Same row split over workgroups (blockIdx.z = split*KS + kh), same
+// part[split][KS*KS][Cout][cin] slabs; any KS / PAD of row a13 (2x2 pad 0: the 4x4 stride-2 layers on the
+// space-to-depth image; 4x4 pad 1: the PatchGAN's stride-1 layers).
+template <typename T, int TH, int TW, int KS, int PAD>
+__global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void convkxk_wgrad_rs_kernel(WgradArgs a) {
+  constexpr bool SPLIT = std::is_same<T, float>::value;
+  constexpr int NIMG = SPLIT ? 3 : 1;
+  constexpr int NT = KS;
+  constexpr int NPX = TH * TW;
+  constexpr int HW_ = TW + KS - 1, HALO = TH * HW_;
+  constexpr int DY_BYTES = 2 * NPX * 64;
+  constexpr int X_BYTES = 2 * HALO * 64;
+  constexpr int DY_PIECES = NPX * 8, DY_IT = (DY_PIECES + 255) / 256;
+  constexpr int X_PIECES = HALO * 8, X_IT = (X_PIECES + 255) / 256;
+  constexpr int KSTEPS = NPX / 16;
+  static_assert(TW % 16 == 0, "a k-step is 16 consecutive pixels of one tile row");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsDY = smem;
+  char* const ldsX = smem + NIMG * DY_BYTES;
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0;
+  const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;
+  const int kh = (int)(blockIdx.z % KS), zsplit = (int)(blockIdx.z / KS);
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  WPiece<T> dreg[DY_IT];
+  WPiece<T> xreg[X_IT];
+
+  auto load_tile = [&](int tile) {
+    int bt = tile;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int img = bt / a.tilesY;
+    const int y0 = ty * TH, xs = tx * TW;
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      const int py = px / TW, pxx = px - py * TW;
+      const int gy = y0 + py, gx = xs + pxx, co = co0 + pc * 8;
+      dreg[i].zero();
+      if (idx < DY_PIECES && gy < a.H && gx < a.W && co < a.Cout)
+        dreg[i].load(dy + ((long)(img * a.H + gy) * a.W + gx) * a.lddy + co);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      const int hy = px / HW_, hx = px - hy * HW_;
+      const int gy = y0 + kh - PAD + hy, gx = xs - PAD + hx, ci = ci0 + pc * 8;
+      xreg[i].zero();
+      if (idx < X_PIECES && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi && ci < cin)
+        xreg[i].load(x0 + ((long)(img * Hi + gy) * Wi + gx) * a.ld0 + ci);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      if (idx < DY_PIECES) dreg[i].to_lds(ldsDY, DY_BYTES, (pc >> 2) * (NPX * 64) + px * 64 + (pc & 3) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx >> 3, pc = idx & 7;
+      if (idx < X_PIECES) xreg[i].to_lds(ldsX, X_BYTES, (pc >> 2) * (HALO * 64) + px * 64 + (pc & 3) * 16);
+    }
+  };
+  const char* const Ahi = ldsDY + wco * (NPX * 64) + frag_off;
+  const char* const Bhi = ldsX + wci * (HALO * 64) + frag_off;
+
+  int tile = zsplit;
+  if (tile < a.ntiles) load_tile(tile);
+  for (; tile < a.ntiles; tile += a.S) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + a.S < a.ntiles) load_tile(tile + a.S);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+      bf16x8 am, al;
+      if constexpr (SPLIT) {
+        am = tr_frag(Ahi + DY_BYTES + m0 * 64, 4 * 64);
+        al = tr_frag(Ahi + 2 * DY_BYTES + m0 * 64, 4 * 64);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int hoff = (py * HW_ + px + t) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        if constexpr (SPLIT) {
+          const bf16x8 bm = tr_frag(Bhi + X_BYTES + hoff, 4 * 64);
+          const bf16x8 bl = tr_frag(Bhi + 2 * X_BYTES + hoff, 4 * 64);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bfr, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bm, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = kh * KS + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (co < a.Cout && ci < cin) a.part[(((long)zsplit * (KS * KS) + tap) * a.Cout + co) * cin + ci] = acc[t][j];
+    }
+  }
+}
+
+// Fold the split slabs of a 4x4 layer straight into nn.Conv2d's [Cout][C][4][4] gradient (what the optimiser's flat
+// buffer holds), in a fixed order:
+//   mode 1 (stride-2 layers, slabs [4 taps (a,b)][Cout][4*C] over the space-to-depth channels (r,s,c)):
+//           grad[o][c][2a+r][2b+s] (+)= sum_z part[z][a*2+b][o][(r*2+s)*C + c]
+//   mode 2 (stride-1 layers, slabs [16 taps (kh,kw)][Cout][C]):  grad[o][c][kh][kw] (+)= sum_z part[z][kh*4+kw][o][c]
+// A workgroup owns one o and 64 consecutive c: its four waves read the sixteen 256-byte rows of every slab, the sums
+// meet in LDS and leave as 1024 contiguous floats.
+__global__ __launch_bounds__(256) void wgrad_fold4x4_kernel(const float* __restrict__ part, float* __restrict__ grad, int S,
+                                                            int Cout, int C, int mode, int accumulate) {
+  __shared__ float tile[16][65];
+  const int o = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long slab = 16L * Cout * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t16 = grp + 4 * i, kh = t16 >> 2, kw = t16 & 3;
+    long src;
+    if (mode == 1) src = ((long)((kh >> 1) * 2 + (kw >> 1)) * Cout + o) * (4L * C) + ((kh & 1) * 2 + (kw & 1)) * C + c0 + cl;
+    else src = ((long)t16 * Cout + o) * C + c0 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c0 + cl < C) {
+      int z = 0;
+      for (; z + 1 < S; z += 2) { s0 += part[(long)z * slab + src]; s1 += part[(long)(z + 1) * slab + src]; }
+      if (z < S) s0 += part[(long)z * slab + src];
+    }
+    tile[t16][cl] = s0 + s1;
+  }
+  __syncthreads();
+  const long base = ((long)o * C + c0) * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = threadIdx.x + i * 256;
+    const int c = k >> 4, t16 = k & 15;
+    if (c0 + c < C) {
+      const float v = tile[t16][c];
+      grad[base + k] = accumulate ? grad[base + k] + v : v;
+    }
+  }
+}
+
 // out[i] (+)= sum_z part[z][i], i < n (n = 4 * Cout * K): the split slabs of the kernel above, folded in a fixed order
 __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long n,
                                                         int accumulate) {
@@ -903,6 +1075,92 @@ extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int
   const long n = 16L * Cout * cin;
   hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad16, a.S, n,
                      accumulate);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// ---- general weight gradient of the row-a13 layers ----------------------------------------------------------------
+// ks = 2: dY [B][H][W][Cout], X [B][H+1][W+1][cin] (the pad-0 operand of s2s_convkxk_nhwc: the space-to-depth image,
+//         cin = 4 C); ks = 4: dY [B][H][W][Cout], X [B][H+1][W+1][cin] (pad 1, cin = C).
+// layout 0: grad[ks*ks][Cout][cin] (the kernel's own tap-major form); layout 1: nn.Conv2d's [Cout][C][4][4] (for the
+// transposed layers call it with the roles of the layer's input and output gradient exchanged: the result is
+// nn.ConvTranspose2d's [Cin][Cout][4][4]).  dtype fp32 = parity mode (register-staged, three-way split).
+// part: float[s2s_convkxk_wgrad_splits()][ks*ks][Cout][cin].
+extern "C" int s2s_convkxk_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout, int ks) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 2 && ks != 4)) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  if (dtype == S2S_BF16 && ks == 2) return conv2x2_wgrad_splits(B, H, W, Cin, Cout);
+  if (dtype == S2S_BF16) return s2s_conv4x4s1_wgrad_splits(B, H, W, Cin, Cout);
+  const int nt = B * cdiv(H, 8) * cdiv(W, 16);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * ks;
+  int s = 512 / mn;
+  if (s > 128) s = 128;
+  if (s > nt) s = nt;
+  if (s < 1) s = 1;
+  return s;
+}
+
+template <typename T, int KS, int PAD>
+static int launch_wgrad_rs(WgradArgs& a, hipStream_t s) {
+  constexpr int TH = 8, TW = 16;
+  constexpr int NIMG = std::is_same<T, float>::value ? 3 : 1;
+  constexpr int lds = NIMG * (2 * TH * TW * 64 + 2 * TH * (TW + KS - 1) * 64);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = convkxk_wgrad_rs_kernel<T, TH, TW, KS, PAD>;
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
+  dim3 grid(cdiv(a.c0, 64), cdiv(a.Cout, 64), a.S * KS);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  return S2S_OK;
+}
+
+extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin,
+                                      float* part, float* grad, int layout, int accumulate, int B, int H, int W, int ks,
+                                      void* stream) {
+  if (!dy || !x || !part || !grad) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (ks != 2 && ks != 4)) return S2S_ERR_SHAPE;
+  if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8) || (layout != 0 && layout != 1)) return S2S_ERR_SHAPE;
+  if (ks == 2 && layout == 1 && (cin % 32)) return S2S_ERR_SHAPE;          // cin = 4 C with C a multiple of 8
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
+  if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
+  WgradArgs a;
+  a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
+  a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
+  a.B = B; a.H = H; a.W = W;
+  a.S = s2s_convkxk_wgrad_splits(dtype, B, H, W, cin, Cout, ks);
+  a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
+  a.ntiles = B * a.tilesY * a.tilesX;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int TH = 8, TW = 16;
+  int rc = S2S_OK;
+  if (dtype == S2S_F32) {
+    rc = ks == 2 ? launch_wgrad_rs<float, 2, 0>(a, s) : launch_wgrad_rs<float, 4, 1>(a, s);
+  } else if (ks == 2) {
+    constexpr int XROWS = ((TH + 1) * (TW + 1) + 31) / 32 * 32;
+    constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
+    auto kern = conv2x2_wgrad_dma_kernel<TH, TW>;
+    static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+    if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc2;
+    hipLaunchKernelGGL(kern, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S), dim3(256), lds, s, a);
+  } else {
+    constexpr int KS = 4;
+    constexpr int XROWS = (TH * (TW + KS - 1) + 31) / 32 * 32;
+    constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
+    auto kern = convkxk_wgrad_rows_kernel<TH, TW, KS, 1>;
+    static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+    if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc2;
+    hipLaunchKernelGGL(kern, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S * KS), dim3(256), lds, s, a);
+  }
+  if (rc != S2S_OK) return rc;
+  if (layout == 0) {
+    const long n = (long)ks * ks * Cout * cin;
+    hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad, a.S, n, accumulate);
+  } else {
+    const int C = ks == 2 ? cin / 4 : cin;
+    hipLaunchKernelGGL(wgrad_fold4x4_kernel, dim3(cdiv(C, 64), Cout), dim3(256), 0, s, part, grad, a.S, Cout, C,
+                       ks == 2 ? 1 : 2, accumulate);
+  }
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -27,8 +27,11 @@ __host__ __device__ inline int in_pcb(int C) {       // channel pieces (of 8) pe
   return p;
 }
 
+// BWD: g is the gradient wrt y = lrelu(z), g2 (optional) the gradient wrt the second output relu(z) of the forward's
+// apply pass: dz = z > 0 ? g + g2 : slope * g.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void in_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ g, int ldg,
+                                                        const T* __restrict__ g2, int ldg2,
                                                         const float* __restrict__ stats, float* __restrict__ part, int B,
                                                         int HW, int C, float slope) {
   const int PCB = in_pcb(C), WL = 256 / PCB;
@@ -46,13 +49,20 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* __restrict__ x,
     }
     const T* const xb = x + (long)n * HW * ldx + c8;
     const T* const gb = BWD ? g + (long)n * HW * ldg + c8 : nullptr;
+    const T* const gb2 = (BWD && g2) ? g2 + (long)n * HW * ldg2 + c8 : nullptr;
     for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
       const f32x8 v = load8(xb + (long)p * ldx);
       if (BWD) {
         const f32x8 gv = load8(gb + (long)p * ldg);
+        f32x8 gw;
+        if (gb2) gw = load8(gb2 + (long)p * ldg2);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gw.v[k] = 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] : slope * gv.v[k];
+          const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw.v[k] : slope * gv.v[k];
           s1[k] += dz;
           s2[k] = fmaf(dz, (v.v[k] - mu[k]) * is[k], s2[k]);
         }
@@ -129,7 +139,8 @@ __global__ void in_affine_grad_kernel(const float* __restrict__ cs, int B, int C
 
 template <typename T>
 __global__ __launch_bounds__(256) void in_lrelu_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
-                                                             T* __restrict__ y, int ldy, int B, int HW, int C, float slope) {
+                                                             T* __restrict__ y, int ldy, T* __restrict__ y2, int ldy2, int B,
+                                                             int HW, int C, float slope) {
   const int PCB = in_pcb(C), WL = 256 / PCB;
   const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
   const int n = blockIdx.z, c8 = (blockIdx.x * PCB + pc) * 8;
@@ -140,20 +151,24 @@ __global__ __launch_bounds__(256) void in_lrelu_apply_kernel(const T* __restrict
   for (int k = 0; k < 8; ++k) { sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
   const T* const xb = x + (long)n * HW * ldx + c8;
   T* const yb = y + (long)n * HW * ldy + c8;
+  T* const yb2 = y2 ? y2 + (long)n * HW * ldy2 + c8 : nullptr;      // relu(z): the skip tensor in the decoder's cat buffer
   for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
     const f32x8 v = load8(xb + (long)p * ldx);
-    f32x8 o8;
+    f32x8 o8, r8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float z = fmaf(v.v[k], sc[k], sh[k]);
       o8.v[k] = z > 0.f ? z : slope * z;
+      r8.v[k] = fmaxf(z, 0.f);
     }
     store8(yb + (long)p * ldy, o8);
+    if (yb2) store8(yb2 + (long)p * ldy2, r8);
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ g2, int ldg2,
+                                                                 const T* __restrict__ x, int ldx,
                                                                  const float* __restrict__ stats, const float* __restrict__ cs,
                                                                  T* __restrict__ dx, int lddx, int B, int HW, int C,
                                                                  float slope) {
@@ -171,14 +186,21 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const T* __rest
   }
   const T* const xb = x + (long)n * HW * ldx + c8;
   const T* const gb = g + (long)n * HW * ldg + c8;
+  const T* const gb2 = g2 ? g2 + (long)n * HW * ldg2 + c8 : nullptr;
   T* const db = dx + (long)n * HW * lddx + c8;
   for (int p = blockIdx.y * WL + wl; p < HW; p += gridDim.y * WL) {
     const f32x8 v = load8(xb + (long)p * ldx);
     const f32x8 gv = load8(gb + (long)p * ldg);
+    f32x8 gw;
+    if (gb2) gw = load8(gb2 + (long)p * ldg2);
+    else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gw.v[k] = 0.f;
+    }
     f32x8 o8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] : slope * gv.v[k];
+      const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw.v[k] : slope * gv.v[k];
       o8.v[k] = sc[k] * (dz - k1[k] - ((v.v[k] - mu[k]) * is[k]) * k2[k]);      // sc = gamma * invstd
     }
     store8(db + (long)p * lddx, o8);
@@ -208,12 +230,14 @@ extern "C" int s2s_instnorm_blocks(int B, int H, int W, int C) {
   return in_blocks(B, H, W, C);
 }
 
-extern "C" int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y,
-                                      int ldy, float* work, float* stats, int B, int H, int W, int C, float eps,
-                                      float slope, void* stream) {
+// y2 (optional, pixel stride ldy2): a second output relu(z) -- the pix2pix generator's ReLU'd skip tensor, written
+// straight into the decoder's concatenation buffer by the same pass.
+extern "C" int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y,
+                                       int ldy, void* y2, int ldy2, float* work, float* stats, int B, int H, int W, int C,
+                                       float eps, float slope, void* stream) {
   if (!x || !y || !work || !stats) return S2S_ERR_NULL;
   if ((gamma == nullptr) != (beta == nullptr)) return S2S_ERR_NULL;
-  if (!in_args_ok(B, H, W, C, ldx, ldy)) return S2S_ERR_SHAPE;
+  if (!in_args_ok(B, H, W, C, ldx, ldy) || (y2 && (ldy2 % 8))) return S2S_ERR_SHAPE;
   if ((long)H * W <= 1) return S2S_ERR_SHAPE;      // torch raises for a single spatial element in training mode
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
@@ -221,11 +245,11 @@ extern "C" int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const f
   const unsigned fin = (unsigned)(((long)B * C + 3) / 4);
 #define S2S_IN_FWD(TT)                                                                                              \
   hipLaunchKernelGGL((in_reduce_kernel<TT, false>), grid, dim3(256), 0, s, (const TT*)x, ldx, (const TT*)nullptr, 0, \
-                     (const float*)nullptr, work, B, HW, C, 0.f);                                                    \
+                     (const TT*)nullptr, 0, (const float*)nullptr, work, B, HW, C, 0.f);                             \
   hipLaunchKernelGGL(in_finalize_kernel, dim3(fin), dim3(256), 0, s, work, nb, B, C, (double)HW, gamma, beta, eps,   \
                      stats);                                                                                         \
-  hipLaunchKernelGGL(in_lrelu_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)x, ldx, stats, (TT*)y, ldy, B, HW, \
-                     C, slope)
+  hipLaunchKernelGGL(in_lrelu_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)x, ldx, stats, (TT*)y, ldy,        \
+                     (TT*)y2, ldy2, B, HW, C, slope)
   if (dtype == S2S_BF16) { S2S_IN_FWD(bf16_t); }
   else if (dtype == S2S_F32) { S2S_IN_FWD(float); }
   else return S2S_ERR_DTYPE;
@@ -234,12 +258,20 @@ extern "C" int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const f
   return S2S_OK;
 }
 
-extern "C" int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const float* stats,
-                                      void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, float* work,
-                                      int B, int H, int W, int C, float slope, void* stream) {
+extern "C" int s2s_instnorm_lrelu_fwd(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y,
+                                      int ldy, float* work, float* stats, int B, int H, int W, int C, float eps,
+                                      float slope, void* stream) {
+  return s2s_instnorm_lrelu_fwd2(dtype, x, ldx, gamma, beta, y, ldy, nullptr, 8, work, stats, B, H, W, C, eps, slope,
+                                 stream);
+}
+
+// g2 (optional): the gradient wrt the forward's second output relu(z); dz = z > 0 ? g + g2 : slope * g.
+extern "C" int s2s_instnorm_lrelu_bwd2(int dtype, const void* g, int ldg, const void* g2, int ldg2, const void* x, int ldx,
+                                       const float* stats, void* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                       float* work, int B, int H, int W, int C, float slope, void* stream) {
   if (!g || !x || !stats || !dx || !work) return S2S_ERR_NULL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return S2S_ERR_NULL;
-  if (!in_args_ok(B, H, W, C, ldx, ldg) || (lddx % 8)) return S2S_ERR_SHAPE;
+  if (!in_args_ok(B, H, W, C, ldx, ldg) || (lddx % 8) || (g2 && (ldg2 % 8))) return S2S_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
   float* const part = work;                                   // [2][B*C][nb]
@@ -248,19 +280,26 @@ extern "C" int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const v
   const unsigned fin = (unsigned)(((long)B * C + 3) / 4);
 #define S2S_IN_BWD(TT)                                                                                              \
   hipLaunchKernelGGL((in_reduce_kernel<TT, true>), grid, dim3(256), 0, s, (const TT*)x, ldx, (const TT*)g, ldg,      \
-                     stats, part, B, HW, C, slope);                                                                  \
+                     (const TT*)g2, ldg2, stats, part, B, HW, C, slope);                                             \
   hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(fin), dim3(256), 0, s, part, nb, B, C, cs);                        \
   if (dgamma)                                                                                                        \
     hipLaunchKernelGGL(in_affine_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, cs, B, C, dgamma, dbeta,          \
                        accumulate);                                                                                  \
-  hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g, ldg, (const TT*)x, ldx,     \
-                     stats, cs, (TT*)dx, lddx, B, HW, C, slope)
+  hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g, ldg, (const TT*)g2, ldg2,   \
+                     (const TT*)x, ldx, stats, cs, (TT*)dx, lddx, B, HW, C, slope)
   if (dtype == S2S_BF16) { S2S_IN_BWD(bf16_t); }
   else if (dtype == S2S_F32) { S2S_IN_BWD(float); }
   else return S2S_ERR_DTYPE;
 #undef S2S_IN_BWD
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+extern "C" int s2s_instnorm_lrelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const float* stats,
+                                      void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, float* work,
+                                      int B, int H, int W, int C, float slope, void* stream) {
+  return s2s_instnorm_lrelu_bwd2(dtype, g, ldg, nullptr, 8, x, ldx, stats, dx, lddx, dgamma, dbeta, accumulate, work, B, H,
+                                 W, C, slope, stream);
 }
 
 // ---- space-to-depth of the zero-padded image and its inverse (row a13) -------------------------------------------
@@ -284,10 +323,8 @@ __global__ __launch_bounds__(256) void s2d_pad1_kernel(const T* __restrict__ src
     const long cell = ((long)n * Hs + (u >> 1)) * Ws + (v >> 1);
     const int sub = ((u & 1) * 2 + (v & 1)) * C + pc * 8;
     const long pix = ((long)n * H + y) * W + x;
-    using V = bf16x8;
-    static_assert(std::is_same<T, bf16_t>::value, "bf16 only");
-    if (INVERSE) *reinterpret_cast<V*>(dst + pix * ldd + pc * 8) = *reinterpret_cast<const V*>(src + cell * lds_ + sub);
-    else *reinterpret_cast<V*>(dst + cell * ldd + sub) = *reinterpret_cast<const V*>(src + pix * lds_ + pc * 8);
+    if (INVERSE) store8(dst + pix * ldd + pc * 8, load8(src + cell * lds_ + sub));     // bf16 <-> fp32 round trip is exact
+    else store8(dst + cell * ldd + sub, load8(src + pix * lds_ + pc * 8));
   }
 }
 
@@ -297,10 +334,9 @@ __global__ __launch_bounds__(256) void s2d_border_zero_kernel(T* __restrict__ ds
   const int cp = C >> 3, Hs = H / 2 + 1, Ws = W / 2 + 1;
   const int per_img = 2 * Ws + 2 * Hs;               // border cells visited per image (corners twice: harmless)
   const long total = (long)B * per_img * 2 * cp;     // x the two sub-positions along the border, x pieces
-  using V = bf16x8;
-  V z;
+  f32x8 z;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = 0;
+  for (int k = 0; k < 8; ++k) z.v[k] = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int pc = (int)(i % cp);
     long t = i / cp;
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(256) void s2d_border_zero_kernel(T* __restrict__ ds
     else if (b < 2 * Ws) { p = Hs - 1; q = b - Ws; r = 1; s = o; }
     else if (b < 2 * Ws + Hs) { p = b - 2 * Ws; q = 0; r = o; s = 0; }
     else { p = b - 2 * Ws - Hs; q = Ws - 1; r = o; s = 1; }
-    *reinterpret_cast<V*>(dst + (((long)n * Hs + p) * Ws + q) * ldd + (r * 2 + s) * C + pc * 8) = z;
+    store8(dst + (((long)n * Hs + p) * Ws + q) * ldd + (r * 2 + s) * C + pc * 8, z);
   }
 }
 
@@ -322,24 +358,30 @@ extern "C" int s2s_space_to_depth_pad1(int dtype, const void* x, int ldx, void* 
                                        int W, int C, void* stream) {
   if (!x || !xs) return S2S_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H % 2) || (W % 2) || (C % 8) || (ldx % 8) || (ldxs % 8)) return S2S_ERR_SHAPE;
-  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)B * H * W * (C / 8);
   long nb = (total + 255) / 256;
   if (nb > 16384) nb = 16384;
-  if (inverse) {       // x = image-shaped destination, xs = source
-    hipLaunchKernelGGL((s2d_pad1_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)xs, ldxs,
-                       (bf16_t*)const_cast<void*>(x), ldx, B, H, W, C);
-  } else {
-    const long bt = (long)B * (2 * (W / 2 + 1) + 2 * (H / 2 + 1)) * 2 * (C / 8);
-    hipLaunchKernelGGL(s2d_border_zero_kernel<bf16_t>, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, s, (bf16_t*)xs,
-                       ldxs, B, H, W, C);
-    hipLaunchKernelGGL((s2d_pad1_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, ldx,
-                       (bf16_t*)xs, ldxs, B, H, W, C);
+  const long bt = (long)B * (2 * (W / 2 + 1) + 2 * (H / 2 + 1)) * 2 * (C / 8);
+#define S2S_S2D(TT)                                                                                                  \
+  if (inverse) { /* x = image-shaped destination, xs = source */                                                      \
+    hipLaunchKernelGGL((s2d_pad1_kernel<TT, true>), dim3((unsigned)nb), dim3(256), 0, s, (const TT*)xs, ldxs,        \
+                       (TT*)const_cast<void*>(x), ldx, B, H, W, C);                                                   \
+  } else {                                                                                                            \
+    hipLaunchKernelGGL(s2d_border_zero_kernel<TT>, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, s, (TT*)xs,      \
+                       ldxs, B, H, W, C);                                                                             \
+    hipLaunchKernelGGL((s2d_pad1_kernel<TT, false>), dim3((unsigned)nb), dim3(256), 0, s, (const TT*)x, ldx,          \
+                       (TT*)xs, ldxs, B, H, W, C);                                                                    \
   }
+  if (dtype == S2S_BF16) { S2S_S2D(bf16_t) } else { S2S_S2D(float) }
+#undef S2S_S2D
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
+
+extern "C" int s2s_pack_conv4x4_t(int dtype, const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride,
+                                  void* stream);
 
 // ---- weight packing for the 4x4 layers (row a13) -----------------------------------------------------------------
 // fp32 master w[Cout][Cin][4][4] -> the two bf16 MFMA operands of s2s_conv2x2_nhwc (stride 2: taps (a,b), k =
@@ -357,26 +399,56 @@ __device__ __forceinline__ float w4x4_at(const float* __restrict__ w, int Cin, i
   return w[(((long)o * Cin + c) * 4 + kh) * 4 + kw];
 }
 
-__global__ __launch_bounds__(256) void pack4x4_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd,
+// one element of the packed pair: e < nf -> forward operand, else data-gradient operand
+template <typename T>
+__device__ __forceinline__ void pack4x4_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
+                                             int stride2, long e) {
+  const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
+  const long nf = (long)((K + 31) / 32) * taps * Cout * 32;
+  if (e < nf) {
+    const int kk = (int)(e & 31);
+    long t = e >> 5;
+    const int o = (int)(t % Cout); t /= Cout;
+    const int tap = (int)(t % taps);
+    const int k = (int)(t / taps) * 32 + kk;
+    wf[e] = from_f32<T>(k < K ? w4x4_at(w, Cin, o, k, tap, stride2) : 0.f);
+  } else {
+    const long d = e - nf;
+    const int oo = (int)(d & 31);
+    long t = d >> 5;
+    const int k = (int)(t % K); t /= K;
+    const int tapf = (int)(t % taps);
+    const int o = (int)(t / taps) * 32 + oo;
+    wd[d] = from_f32<T>(o < Cout ? w4x4_at(w, Cin, o, k, taps - 1 - tapf, stride2) : 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack4x4_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                                       int Cout, int Cin, int stride2) {
   const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
-  const long nf = (long)((K + 31) / 32) * taps * Cout * 32, nd = (long)((Cout + 31) / 32) * taps * K * 32;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += (long)gridDim.x * 256) {
-    if (e < nf) {
-      const int kk = (int)(e & 31);
-      long t = e >> 5;
-      const int o = (int)(t % Cout); t /= Cout;
-      const int tap = (int)(t % taps);
-      const int k = (int)(t / taps) * 32 + kk;
-      wf[e] = (bf16_t)(k < K ? w4x4_at(w, Cin, o, k, tap, stride2) : 0.f);
-    } else {
-      const long d = e - nf;
-      const int oo = (int)(d & 31);
-      long t = d >> 5;
-      const int k = (int)(t % K); t /= K;
-      const int tapf = (int)(t % taps);
-      const int o = (int)(t / taps) * 32 + oo;
-      wd[d] = (bf16_t)(o < Cout ? w4x4_at(w, Cin, o, k, taps - 1 - tapf, stride2) : 0.f);
+  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+    pack4x4_elem<T>(w, wf, wd, Cout, Cin, stride2, e);
+}
+
+// every 4x4 layer of a network in one launch (after the fused Adam step): desc[l] = {w, wf, wd, Cout, Cin, stride2,
+// first block}; a workgroup handles 2048 consecutive elements of its layer's packed pair
+__global__ __launch_bounds__(256) void pack4x4_batched_kernel(const long* __restrict__ desc, int nlayers, int dtype) {
+  int l = 0;
+  while (l + 1 < nlayers && (long)blockIdx.x >= desc[(l + 1) * 7 + 6]) ++l;
+  const long* d = desc + l * 7;
+  const float* w = reinterpret_cast<const float*>(d[0]);
+  const int Cout = (int)d[3], Cin = (int)d[4], stride2 = (int)d[5];
+  const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
+  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+  const long e0 = ((long)blockIdx.x - d[6]) * 2048;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long e = e0 + i * 256 + threadIdx.x;
+    if (e < n) {
+      if (dtype == S2S_BF16) pack4x4_elem<bf16_t>(w, reinterpret_cast<bf16_t*>(d[1]), reinterpret_cast<bf16_t*>(d[2]), Cout, Cin, stride2, e);
+      else pack4x4_elem<float>(w, reinterpret_cast<float*>(d[1]), reinterpret_cast<float*>(d[2]), Cout, Cin, stride2, e);
     }
   }
 }
@@ -384,14 +456,44 @@ __global__ __launch_bounds__(256) void pack4x4_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" int s2s_pack_conv4x4(const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride, void* stream) {
+  return s2s_pack_conv4x4_t(S2S_BF16, w_oihw, wf, wd, Cout, Cin, stride, stream);
+}
+
+// wf / wd in the activation dtype (fp32: the parity mode's kernels split the operands into three bf16 on the fly)
+extern "C" int s2s_pack_conv4x4_t(int dtype, const float* w_oihw, void* wf, void* wd, int Cout, int Cin, int stride,
+                                  void* stream) {
   if (!w_oihw || !wf || !wd) return S2S_ERR_NULL;
   if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2)) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   const int taps = stride == 2 ? 4 : 16, K = stride == 2 ? 4 * Cin : Cin;
   const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
   long nb = (n + 255) / 256;
   if (nb > 65535) nb = 65535;
-  hipLaunchKernelGGL(pack4x4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)wf,
-                     (bf16_t*)wd, Cout, Cin, stride == 2 ? 1 : 0);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(pack4x4_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)wf,
+                       (bf16_t*)wd, Cout, Cin, stride == 2 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(pack4x4_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)wf,
+                       (float*)wd, Cout, Cin, stride == 2 ? 1 : 0);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// blocks a layer occupies in the batched launch (the caller accumulates them into desc[l][6])
+extern "C" long s2s_pack_conv4x4_blocks(int Cout, int Cin, int stride) {
+  if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2)) return S2S_ERR_SHAPE;
+  const int taps = stride == 2 ? 4 : 16, K = stride == 2 ? 4 * Cin : Cin;
+  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+  return (n + 2047) / 2048;
+}
+
+// desc: device long[nlayers][7] = {w (fp32 master), wf, wd, Cout, Cin, stride == 2, first block}; total = all blocks
+extern "C" int s2s_pack_conv4x4_batched(int dtype, const void* desc, int nlayers, long total, void* stream) {
+  if (!desc) return S2S_ERR_NULL;
+  if (nlayers <= 0 || total <= 0 || total >= (1L << 31)) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  hipLaunchKernelGGL(pack4x4_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
+                     nlayers, dtype);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -426,10 +528,10 @@ extern "C" int s2s_channel_sum(int dtype, const void* x, int ldx, float* work, f
   const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, 1);
   if (dtype == S2S_BF16)
     hipLaunchKernelGGL((in_reduce_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)nullptr,
-                       0, (const float*)nullptr, work, 1, (int)npix, C, 0.f);
+                       0, (const bf16_t*)nullptr, 0, (const float*)nullptr, work, 1, (int)npix, C, 0.f);
   else if (dtype == S2S_F32)
     hipLaunchKernelGGL((in_reduce_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, ldx, (const float*)nullptr, 0,
-                       (const float*)nullptr, work, 1, (int)npix, C, 0.f);
+                       (const float*)nullptr, 0, (const float*)nullptr, work, 1, (int)npix, C, 0.f);
   else return S2S_ERR_DTYPE;
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, work, nb, C, out,
                      accumulate);

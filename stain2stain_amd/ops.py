@@ -36,7 +36,7 @@ def _nhwc(t: torch.Tensor) -> Tuple[int, int]:
     if t.dim() != 4 or t.stride(3) != 1:
         raise RuntimeError("stain2stain_amd: expected an NHWC view with contiguous channels")
     b, h, w, _ = t.shape
-    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else t.shape[3])
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if b > 1 else t.shape[3]))
     if w > 1 and h > 1 and t.stride(1) != w * ld:
         raise RuntimeError("stain2stain_amd: NHWC view has a row pitch")
     if b > 1 and t.stride(0) != h * w * ld:
@@ -752,3 +752,230 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
     rc = _L().s2s_channel_sum(_dt(x), px, ldx, _f32(work), _f32(out), npix, C, 0, _stream())
     _native.check(rc, "channel_sum")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# pix2pix G + D step (row a13): general 4x4-layer kernels in both dtypes, fused elementwise / loss kernels
+# ------------------------------------------------------------------------------------------------
+def _kxk_flops(x, w_packed, bias, cout, ks, pad, **kw) -> float:
+    B, Hi, Wi, cin = x.shape
+    H, W = Hi - (ks - 1) + 2 * pad, Wi - (ks - 1) + 2 * pad
+    return 2.0 * B * H * W * cout * ks * ks * cin
+
+
+@_timed("convkxk_mfma", _kxk_flops)
+def convkxk(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ks: int, pad: int, *,
+            act: bool = False, slope: float = 0.0, out: Optional[torch.Tensor] = None,
+            out2: Optional[torch.Tensor] = None, bias_mod: int = 0) -> torch.Tensor:
+    """KS x KS-tap convolution of the 4x4 layers (see s2s_convkxk_nhwc): ks = 2 / pad 0 | 1 = stride-2 convolution on the
+    space-to-depth image | transposed form; ks = 4 / pad 1 | 2 = stride-1 convolution | its data gradient.
+    ``act``: LeakyReLU(slope) on the bias-added output; ``out2`` receives relu(output) (a view with its own stride)."""
+    B, Hi, Wi, cin = x.shape
+    H, W = Hi - (ks - 1) + 2 * pad, Wi - (ks - 1) + 2 * pad
+    if w_packed.dtype != x.dtype or w_packed.numel() != ((cin + 31) // 32) * ks * ks * cout * 32:
+        raise RuntimeError("stain2stain_amd: convkxk packed weight does not match (cout, cin, ks, dtype)")
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device) if out is None else out
+    if tuple(y.shape) != (B, H, W, cout) or y.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: convkxk output buffer mismatch")
+    py, ldy = _nhwc(y)
+    p2, ld2 = 0, 8
+    if out2 is not None:
+        if tuple(out2.shape) != (B, H, W, cout) or out2.dtype != x.dtype:
+            raise RuntimeError("stain2stain_amd: convkxk second output mismatch")
+        p2, ld2 = _nhwc(out2)
+    if bias is not None and bias.numel() != (bias_mod or cout):
+        raise RuntimeError("stain2stain_amd: convkxk bias length does not match (cout, bias_mod)")
+    rc = _L().s2s_convkxk_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), int(bias_mod), py, ldy, p2, ld2, int(act),
+                               float(slope), 0, B, H, W, cout, ks, pad, _stream())
+    _native.check(rc, "convkxk")
+    return y
+
+
+def _kxk_wgrad_flops(dy, x, grad, ks, **kw) -> float:
+    B, H, W, cout = dy.shape
+    return 2.0 * B * H * W * cout * ks * ks * x.shape[3]
+
+
+@_timed("convkxk_wgrad_mfma", _kxk_wgrad_flops)
+def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int, accumulate: bool = False) -> None:
+    """grad (fp32, nn.Conv2d layout [Cout][C][4][4]) (+)= weight gradient: dy [B,H,W,Cout]; x [B,H+1,W+1,cin] with
+    cin = 4 C (ks = 2, space-to-depth image) or C (ks = 4)."""
+    B, H, W, cout = dy.shape
+    cin = x.shape[3]
+    C = cin // 4 if ks == 2 else cin
+    if x.dtype != dy.dtype or tuple(x.shape[:3]) != (B, H + 1, W + 1):
+        raise RuntimeError("stain2stain_amd: convkxk_wgrad operand mismatch")
+    if grad.numel() != cout * C * 16 or grad.dtype != torch.float32 or not grad.is_contiguous():
+        raise RuntimeError("stain2stain_amd: convkxk_wgrad gradient buffer has the wrong size")
+    pdy, lddy = _nhwc(dy)
+    px, ldx = _nhwc(x)
+    s = _L().s2s_convkxk_wgrad_splits(_dt(dy), B, H, W, cin, cout, ks)
+    _native.check(min(s, 0), "convkxk_wgrad_splits")
+    part = torch.empty((s, ks * ks, cout, cin), dtype=torch.float32, device=dy.device)
+    rc = _L().s2s_convkxk_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), grad.data_ptr(), 1,
+                                     int(accumulate), B, H, W, ks, _stream())
+    _native.check(rc, "convkxk_wgrad")
+
+
+@_timed("instnorm_lrelu_fwd")
+def instnorm_lrelu_fwd2(x: torch.Tensor, slope: float, out: torch.Tensor, out2: Optional[torch.Tensor] = None,
+                        eps: float = 1e-5):
+    """out = leaky_relu(instance_norm(x), slope), out2 (optional view) = relu(instance_norm(x)); returns stats[4][B][C]."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    py, ldy = _nhwc(out)
+    p2, ld2 = (0, 8) if out2 is None else _nhwc(out2)
+    nb = _L().s2s_instnorm_blocks(B, H, W, C)
+    _native.check(min(nb, 0), "instnorm_blocks")
+    work = torch.empty(2 * B * C * nb, dtype=torch.float32, device=x.device)
+    stats = torch.empty((4, B, C), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_instnorm_lrelu_fwd2(_dt(x), px, ldx, 0, 0, py, ldy, p2, ld2, _f32(work), _f32(stats), B, H, W, C, eps,
+                                      slope, _stream())
+    _native.check(rc, "instnorm_lrelu_fwd2")
+    return stats
+
+
+@_timed("instnorm_lrelu_bwd")
+def instnorm_lrelu_bwd2(g: torch.Tensor, g2: Optional[torch.Tensor], x: torch.Tensor, stats: torch.Tensor,
+                        slope: float) -> torch.Tensor:
+    """dx of InstanceNorm + LeakyReLU for the gradients g (wrt the LeakyReLU output) and g2 (wrt the relu copy)."""
+    B, H, W, C = x.shape
+    pg, ldg = _nhwc(g)
+    p2, ld2 = (0, 8) if g2 is None else _nhwc(g2)
+    px, ldx = _nhwc(x)
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    nb = _L().s2s_instnorm_blocks(B, H, W, C)
+    _native.check(min(nb, 0), "instnorm_blocks")
+    work = torch.empty(2 * B * C * nb + 2 * B * C, dtype=torch.float32, device=x.device)
+    rc = _L().s2s_instnorm_lrelu_bwd2(_dt(x), pg, ldg, p2, ld2, px, ldx, _f32(stats), dx.data_ptr(), C, 0, 0, 0,
+                                      _f32(work), B, H, W, C, slope, _stream())
+    _native.check(rc, "instnorm_lrelu_bwd2")
+    return dx
+
+
+def pack_conv4x4_t(w: torch.Tensor, stride: int, dtype: torch.dtype):
+    """pack_conv4x4 with the operands in ``dtype`` (bf16 or fp32)."""
+    cout, cin = w.shape[:2]
+    taps, K = (4, 4 * cin) if stride == 2 else (16, cin)
+    wf = torch.empty(((K + 31) // 32, taps, cout, 32), dtype=dtype, device=w.device)
+    wd = torch.empty(((cout + 31) // 32, taps, K, 32), dtype=dtype, device=w.device)
+    rc = _L().s2s_pack_conv4x4_t(_dt(wf), _f32(w.detach().contiguous()), wf.data_ptr(), wd.data_ptr(), cout, cin, stride,
+                                 _stream())
+    _native.check(rc, "pack_conv4x4_t")
+    return wf, wd
+
+
+@_timed("pack_conv4x4")
+def pack_conv4x4_batched(desc: torch.Tensor, total: int, dtype: torch.dtype) -> None:
+    """desc: int64 [nlayers, 7] device tensor {w, wf, wd, Cout, Cin, stride == 2, first block}."""
+    code = BF16 if dtype == torch.bfloat16 else F32
+    _native.check(_L().s2s_pack_conv4x4_batched(code, desc.data_ptr(), desc.shape[0], int(total), _stream()),
+                  "pack_conv4x4_batched")
+
+
+def space_to_depth_pad1_t(x: torch.Tensor) -> torch.Tensor:
+    """space_to_depth_pad1 for either dtype."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    xs = torch.empty((B, H // 2 + 1, W // 2 + 1, 4 * C), dtype=x.dtype, device=x.device)
+    rc = _L().s2s_space_to_depth_pad1(_dt(x), px, ldx, xs.data_ptr(), 4 * C, 0, B, H, W, C, _stream())
+    _native.check(rc, "space_to_depth_pad1")
+    return xs
+
+
+def depth_to_space_unpad1_t(xs: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, Hs, Ws, C4 = xs.shape
+    H, W, C = 2 * (Hs - 1), 2 * (Ws - 1), C4 // 4
+    pxs, ldxs = _nhwc(xs)
+    x = torch.empty((B, H, W, C), dtype=xs.dtype, device=xs.device) if out is None else out
+    px, ldx = _nhwc(x)
+    rc = _L().s2s_space_to_depth_pad1(_dt(xs), px, ldx, pxs, ldxs, 1, B, H, W, C, _stream())
+    _native.check(rc, "depth_to_space_unpad1")
+    return x
+
+
+def p2p_pack_input(a: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """out[B,H,W,8] <- [a | b | 0]; a, b NCHW fp32."""
+    B, ca, H, W = a.shape
+    cb = 0 if b is None else b.shape[1]
+    po, ldo = _nhwc(out)
+    rc = _L().s2s_p2p_pack_input(_dt(out), _f32(a), ca, _f32(b), cb, po, ldo, B, H, W, _stream())
+    _native.check(rc, "p2p_pack_input")
+    return out
+
+
+@_timed("p2p_tanh_l1_fwd")
+def p2p_tanh_l1_fwd(h: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor, d_in: torch.Tensor,
+                    fake_nchw: Optional[torch.Tensor] = None, l1_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fake = tanh(h[..., :C]); d_in <- [src | fake | 0]; returns (and writes to ``l1_out[0]``) mean |fake - tgt|."""
+    B, H, W, _ = h.shape
+    C = tgt.shape[1]
+    ph, ldh = _nhwc(h)
+    pd, ldd = _nhwc(d_in)
+    nb = _L().s2s_p2p_tanh_l1_blocks(B, H, W)
+    work = torch.empty((nb,), dtype=torch.float64, device=h.device)
+    l1 = torch.empty((1,), dtype=torch.float32, device=h.device) if l1_out is None else l1_out
+    rc = _L().s2s_p2p_tanh_l1_fwd(_dt(h), ph, ldh, _f32(src), _f32(tgt), pd, ldd, _f32(fake_nchw), _f32(l1),
+                                  work.data_ptr(), B, H, W, C, _stream())
+    _native.check(rc, "p2p_tanh_l1_fwd")
+    return l1
+
+
+@_timed("p2p_tanh_l1_bwd")
+def p2p_tanh_l1_bwd(h: torch.Tensor, tgt: torch.Tensor, gd: Optional[torch.Tensor], l1_scale: float) -> torch.Tensor:
+    B, H, W, _ = h.shape
+    C = tgt.shape[1]
+    ph, ldh = _nhwc(h)
+    pg, ldg = (0, 8) if gd is None else _nhwc(gd)
+    dh = torch.empty((B, H, W, 8), dtype=h.dtype, device=h.device)
+    rc = _L().s2s_p2p_tanh_l1_bwd(_dt(h), ph, ldh, _f32(tgt), pg, ldg, float(l1_scale), dh.data_ptr(), 8, B, H, W, C,
+                                  _stream())
+    _native.check(rc, "p2p_tanh_l1_bwd")
+    return dh
+
+
+def p2p_bce_logits(z: torch.Tensor, n_real: int, w_real: float, w_fake: float, want_grad: bool = True,
+                   out: Optional[torch.Tensor] = None):
+    """z [N,H,W,8] (logit = channel 0): (out[2] = mean softplus(-z) over the first n_real samples, mean softplus(z) over
+    the others; dz [N,H,W,8] or None)."""
+    N, H, W, _ = z.shape
+    pz, ldz = _nhwc(z)
+    dz = torch.empty((N, H, W, 8), dtype=z.dtype, device=z.device) if want_grad else None
+    if out is None:
+        out = torch.empty((2,), dtype=torch.float32, device=z.device)
+    rc = _L().s2s_p2p_bce_logits(_dt(z), pz, ldz, int(n_real), float(w_real), float(w_fake),
+                                 0 if dz is None else dz.data_ptr(), 8, _f32(out), N, H * W, _stream())
+    _native.check(rc, "p2p_bce_logits")
+    return out, dz
+
+
+@_timed("p2p_act_bwd")
+def p2p_act_bwd(g: torch.Tensor, g2: Optional[torch.Tensor], a: torch.Tensor, slope: float,
+                dbias: Optional[torch.Tensor]) -> torch.Tensor:
+    """dz = a > 0 ? g + g2 : slope * g; dbias (fp32 [C]) <- per-channel sum of dz."""
+    B, H, W, C = a.shape
+    npix = B * H * W
+    pg, ldg = _nhwc(g)
+    p2, ld2 = (0, 8) if g2 is None else _nhwc(g2)
+    pa, lda = _nhwc(a)
+    dz = torch.empty((B, H, W, C), dtype=a.dtype, device=a.device)
+    nb = _L().s2s_p2p_act_bwd_blocks(npix, C)
+    _native.check(min(nb, 0), "p2p_act_bwd_blocks")
+    work = torch.empty((C * nb,), dtype=torch.float32, device=a.device)
+    rc = _L().s2s_p2p_act_bwd(_dt(a), pg, ldg, p2, ld2, pa, lda, float(slope), dz.data_ptr(), C, _f32(work),
+                              0 if dbias is None else dbias.data_ptr(), 0, npix, C, _stream())
+    _native.check(rc, "p2p_act_bwd")
+    return dz
+
+
+def channel_sum_into(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[C] (fp32) <- per-channel sum of an NHWC tensor (conv-bias gradient)."""
+    B, H, W, C = x.shape
+    px, ldx = _nhwc(x)
+    npix = B * H * W
+    nb = _L().s2s_channel_sum_blocks(npix, C)
+    _native.check(min(nb, 0), "channel_sum_blocks")
+    work = torch.empty(2 * C * nb, dtype=torch.float32, device=x.device)
+    rc = _L().s2s_channel_sum(_dt(x), px, ldx, _f32(work), out.data_ptr(), npix, C, 0, _stream())
+    _native.check(rc, "channel_sum")

@@ -1,0 +1,418 @@
+"""The pix2pix G + D optimisation step without autograd and without torch math.
+
+BASELINE.json's north_star opens with this path ("pix2pix-style U-Net generator + PatchGAN discriminator forward /
+backward ... fused InstanceNorm+LeakyReLU") and its ``metric`` is worded on it ("G+D step"); the reference repository
+holds no such model, so the semantics are those of ``oracle/pix2pix_oracle.py`` -- the same two networks
+built from torch's own layers -- and parity with the reference is unpinned by construction.
+
+One step (``Pix2PixTrainer.step``), every launch a HIP kernel of libstain2stain_hip.so:
+
+    fake            <- G(src)                                   (generator forward, tanh head)
+    D update        <- BCE(D(src, tgt), 1) / 2 + BCE(D(src, fake.detach()), 0) / 2
+                       real and fake ride through D as ONE batch of 2B samples (InstanceNorm is per sample, so the
+                       result equals two passes); discriminator backward, [all-reduce], fused Adam, repack
+    G update        <- BCE(D(src, fake), 1) + lambda * L1(fake, tgt) through the UPDATED D (data gradient only: no
+                       discriminator weight gradients are formed), generator backward, [all-reduce], fused Adam, repack
+
+Layout: NHWC, bf16 (throughput) or fp32 (three-way-split parity mode); images padded to 8 channels.  The 4x4 stride-2
+convolution is a 2x2 convolution over the space-to-depth image of its padded input, the transposed convolution the same
+loop with flipped taps (conv3x3_mfma.hip, convkxk).  The skip connections never materialise ``torch.cat``: the encoder's
+norm pass writes relu(z) into the first half of the decoder's concatenation buffer and the decoder's norm pass writes its
+output into the second half.  Parameters, gradients and Adam moments of each network live in flat fp32 buffers in
+backward-completion order (``trainer.FlatParams``), so gradient buckets are contiguous slices.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .ddp import GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
+from .pix2pix import PatchGANDiscriminator, Pix2PixGenerator
+
+LRELU = 0.2
+
+
+class FlatParams:
+    """Parameters of one network as views of a flat fp32 buffer + flat gradient / Adam-moment buffers.
+
+    ``groups``: [[(name, parameter), ...], ...] in the order the backward pass completes them."""
+
+    def __init__(self, groups: List[List[Tuple[str, torch.nn.Parameter]]], bucket_mb: float, process_group):
+        dev = groups[0][0][1].device
+        sizes, offs, off = [], {}, 0
+        for g in groups:
+            start = off
+            for name, p in g:
+                offs[name] = off
+                off += (p.numel() + 7) // 8 * 8            # 32-byte aligned views
+            sizes.append(off - start)
+        self.p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.slot: Dict[str, Tuple[int, int]] = {}
+        with torch.no_grad():
+            for g in groups:
+                for name, p in g:
+                    o, n = offs[name], p.numel()
+                    self.p[o:o + n].copy_(p.detach().reshape(-1))
+                    p.data = self.p[o:o + n].view(p.shape)
+                    p.grad = self.g[o:o + n].view(p.shape)
+                    self.grads[name] = p.grad
+                    self.slot[name] = (o, n)
+        self.bucketer = GradBucketer(self.g, sizes, bucket_mb, process_group)
+        self.step_count = 0
+        broadcast_from_rank0([self.p], process_group)
+
+    def adam(self, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float) -> None:
+        self.bucketer.wait_all()
+        self.step_count += 1
+        ops.adam_step_(self.p, self.g, self.m, self.v, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
+                       self.bucketer.grad_scale)
+
+
+@dataclass
+class _Layer:
+    """One 4x4 layer: fp32 master weight / bias (views of the flat buffer) + its two packed MFMA operands."""
+    name: str
+    kind: str                           # "s2" conv stride 2, "t2" transposed conv stride 2, "s1" conv stride 1
+    weight: torch.nn.Parameter
+    bias: Optional[torch.nn.Parameter]
+    wf: torch.Tensor = None
+    wd: torch.Tensor = None
+
+    @property
+    def conv_out(self) -> int:          # output channels of the layer
+        return self.weight.shape[1] if self.kind == "t2" else self.weight.shape[0]
+
+    @property
+    def conv_in(self) -> int:
+        return self.weight.shape[0] if self.kind == "t2" else self.weight.shape[1]
+
+
+class _Packer:
+    """(Re)packs every layer of a network in one launch (s2s_pack_conv4x4_batched)."""
+
+    def __init__(self, layers: List[_Layer], dtype: torch.dtype):
+        self.layers, self.dtype = layers, dtype
+        rows, start = [], 0
+        L = ops._L()
+        for l in layers:
+            w = l.weight
+            o, c = w.shape[0], w.shape[1]                      # nn.ConvTranspose2d's [Cin, Cout] is read as Conv2d's [O, C]
+            stride = 1 if l.kind == "s1" else 2
+            taps, K = (4, 4 * c) if stride == 2 else (16, c)
+            l.wf = torch.empty(((K + 31) // 32, taps, o, 32), dtype=dtype, device=w.device)
+            l.wd = torch.empty(((o + 31) // 32, taps, K, 32), dtype=dtype, device=w.device)
+            rows.append([w.data_ptr(), l.wf.data_ptr(), l.wd.data_ptr(), o, c, 1 if stride == 2 else 0, start])
+            start += L.s2s_pack_conv4x4_blocks(o, c, stride)
+        self.desc = torch.tensor(rows, dtype=torch.int64, device=layers[0].weight.device)
+        self.total = start
+        self.repack()
+
+    def repack(self) -> None:
+        ops.pack_conv4x4_batched(self.desc, self.total, self.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# layer forward / backward on the kernels
+# ----------------------------------------------------------------------------------------------------------------------
+def _conv_s2_fwd(l: _Layer, xs: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None) -> torch.Tensor:
+    """nn.Conv2d(k=4, s=2, p=1) from the space-to-depth image xs of its input."""
+    return ops.convkxk(xs, l.wf, None if l.bias is None else l.bias.detach(), l.conv_out, 2, 0, act=act, slope=slope,
+                       out2=out2)
+
+
+def _conv_s2_bwd(l: _Layer, g: torch.Tensor, xs: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True):
+    if want_w:
+        ops.convkxk_wgrad(g, xs, gw, 2)
+    if not need_dx:
+        return None
+    return ops.depth_to_space_unpad1_t(ops.convkxk(g, l.wd, None, 4 * l.conv_in, 2, 1))
+
+
+def _conv_t2_fwd(l: _Layer, x: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose2d(k=4, s=2, p=1): [B,h,w,Cin] -> [B,2h,2w,Cout]."""
+    # the four sub-pixel channel groups of the space-to-depth output share the layer's bias (bias_mod)
+    return ops.depth_to_space_unpad1_t(ops.convkxk(x, l.wd, None if l.bias is None else l.bias.detach(), 4 * l.conv_out, 2,
+                                                   1, bias_mod=l.conv_out))
+
+
+def _conv_t2_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, need_dx: bool = True):
+    gs = ops.space_to_depth_pad1_t(g)
+    ops.convkxk_wgrad(x, gs, gw, 2)              # roles exchanged: the result is nn.ConvTranspose2d's [Cin][Cout][4][4]
+    return ops.convkxk(gs, l.wf, None, l.conv_in, 2, 0) if need_dx else None
+
+
+def _conv_s1_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, want_w: bool = True) -> torch.Tensor:
+    if want_w:
+        ops.convkxk_wgrad(g, x, gw, 4)
+    return ops.convkxk(g, l.wd, None, l.conv_in, 4, 2)
+
+
+@dataclass
+class _GCtx:
+    xs: List[torch.Tensor] = field(default_factory=list)        # space-to-depth input of every down layer
+    raw: List[Optional[torch.Tensor]] = field(default_factory=list)   # conv output ahead of a norm (None: no norm)
+    act: List[torch.Tensor] = field(default_factory=list)       # down-layer activations a_i
+    stats: List[Optional[torch.Tensor]] = field(default_factory=list)
+    cat: List[torch.Tensor] = field(default_factory=list)       # input of up layer j ([relu(skip) | u_{j-1}])
+    uraw: List[torch.Tensor] = field(default_factory=list)      # transposed-conv output ahead of its norm
+    ustats: List[torch.Tensor] = field(default_factory=list)
+    h: torch.Tensor = None                                      # pre-tanh output [B,H,W,8]
+
+
+class Pix2PixTrainer:
+    """Fused G + D training step for ``Pix2PixGenerator`` / ``PatchGANDiscriminator`` (their parameters become views of
+    this trainer's flat buffers; ``state_dict`` / ``load_state_dict`` of the modules keep working).
+
+    ``precision``: "bf16" (throughput) or "fp32" (three-way-split MFMA parity mode, checked at 1e-3 against the oracle).
+    """
+
+    def __init__(self, G: Pix2PixGenerator, D: PatchGANDiscriminator, lr: float = 2e-4,
+                 betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 lambda_l1: float = 100.0, precision: str = "bf16", bucket_mb: float = 16.0, process_group=None,
+                 sync_loss: bool = True):
+        dev = next(G.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("stain2stain_amd: Pix2PixTrainer needs the networks on a GPU (HIP-only implementation)")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.G, self.D = G, D
+        self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.lr, self.betas, self.eps, self.wd, self.lambda_l1 = lr, tuple(betas), eps, weight_decay, lambda_l1
+        self.pg, self.sync_loss = process_group, sync_loss
+        n = len(G.downs)
+        self.n = n
+        self.g_down = [_Layer(f"downs.{i}", "s2", m.weight, m.bias) for i, m in enumerate(G.downs)]
+        self.g_up = [_Layer(f"ups.{j}", "t2", m.weight, m.bias) for j, m in enumerate(G.ups)]
+        self.d_layers = [_Layer("c1", "s2", D.c1.weight, D.c1.bias), _Layer("c2", "s2", D.c2.weight, D.c2.bias),
+                         _Layer("c3", "s2", D.c3.weight, D.c3.bias), _Layer("c4", "s1", D.c4.weight, D.c4.bias),
+                         _Layer("c5", "s1", D.c5.weight, D.c5.bias)]
+
+        def group(l: _Layer):
+            return [(l.name + ".weight", l.weight)] + ([(l.name + ".bias", l.bias)] if l.bias is not None else [])
+
+        # backward-completion order: last up layer first ... first down layer last; D: c5 ... c1
+        self.pG = FlatParams([group(l) for l in reversed(self.g_up)] + [group(l) for l in reversed(self.g_down)],
+                             bucket_mb, process_group)
+        self.pD = FlatParams([group(l) for l in reversed(self.d_layers)], bucket_mb, process_group)
+        self.packG = _Packer(self.g_down + self.g_up, self.dtype)
+        self.packD = _Packer(self.d_layers, self.dtype)
+        self.in_channels, self.out_channels = G.in_channels, G.out_channels
+        self.last: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    # generator
+    # ------------------------------------------------------------------------------------------------------------
+    def g_forward(self, src: torch.Tensor) -> _GCtx:
+        """src: NCHW fp32 [B, in_channels, H, W] -> ctx with ctx.h = pre-tanh output [B,H,W,8]."""
+        n, dt = self.n, self.dtype
+        B, _, H, W = src.shape
+        if H % (1 << n) or W % (1 << n):
+            raise ValueError(f"tile size must be a multiple of {1 << n} for {n} down-sampling layers")
+        dev = src.device
+        ctx = _GCtx()
+        ch = [l.conv_out for l in self.g_down]
+        # concatenation buffers of the up path: cat[j] = [relu(a_{n-1-j}) | u_{j-1}], j >= 1
+        ctx.cat = [None] * n
+        for j in range(1, n):
+            i = n - 1 - j
+            ctx.cat[j] = torch.empty((B, H >> (i + 1), W >> (i + 1), 2 * ch[i]), dtype=dt, device=dev)
+        x = ops.p2p_pack_input(src, None, torch.empty((B, H, W, 8), dtype=dt, device=dev))
+        for i, l in enumerate(self.g_down):
+            xs = ops.space_to_depth_pad1_t(x)
+            ctx.xs.append(xs)
+            skip = ctx.cat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
+            if i == 0:                                    # LeakyReLU, no norm
+                a = _conv_s2_fwd(l, xs, act=True, slope=LRELU, out2=skip)
+                ctx.raw.append(None); ctx.stats.append(None)
+            elif i == n - 1:                              # innermost: ReLU, no norm
+                a = _conv_s2_fwd(l, xs, act=True, slope=0.0)
+                ctx.raw.append(None); ctx.stats.append(None)
+            else:
+                raw = _conv_s2_fwd(l, xs)
+                a = torch.empty_like(raw)
+                ctx.stats.append(ops.instnorm_lrelu_fwd2(raw, LRELU, a, skip))
+                ctx.raw.append(raw)
+            ctx.act.append(a)
+            x = a
+        for j, l in enumerate(self.g_up):
+            xin = x if j == 0 else ctx.cat[j]
+            hraw = _conv_t2_fwd(l, xin)
+            if j < n - 1:
+                C = l.conv_out
+                ctx.ustats.append(ops.instnorm_lrelu_fwd2(hraw, 0.0, ctx.cat[j + 1][..., C:]))
+                ctx.uraw.append(hraw)
+            else:
+                ctx.h = hraw
+        return ctx
+
+    def g_backward(self, ctx: _GCtx, dh: torch.Tensor) -> None:
+        """dh: gradient wrt the pre-tanh output.  Gradients go to the flat buffer; buckets are launched as they close."""
+        n, gr, bk = self.n, self.pG.grads, self.pG.bucketer
+        bk.start_step()
+        ch = [l.conv_out for l in self.g_down]
+        grp = 0
+        g = dh
+        dcat = [None] * n
+        for j in range(n - 1, -1, -1):
+            l = self.g_up[j]
+            if j == n - 1:
+                if l.bias is not None:
+                    ops.channel_sum_into(g, gr[l.name + ".bias"])
+            else:
+                C = l.conv_out
+                g = ops.instnorm_lrelu_bwd2(dcat[j + 1][..., C:], None, ctx.uraw[j], ctx.ustats[j], 0.0)
+            xin = ctx.act[n - 1] if j == 0 else ctx.cat[j]
+            dx = _conv_t2_bwd(l, g, xin, gr[l.name + ".weight"])
+            if j == 0:
+                g = dx
+            else:
+                dcat[j] = dx
+            bk.mark_ready(grp); grp += 1
+        for i in range(n - 1, -1, -1):
+            l = self.g_down[i]
+            skip_g = dcat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
+            if i == n - 1:
+                g = ops.p2p_act_bwd(g, None, ctx.act[i], 0.0, gr.get(l.name + ".bias"))
+            elif i == 0:
+                g = ops.p2p_act_bwd(g, skip_g, ctx.act[0], LRELU, gr.get(l.name + ".bias"))
+            else:
+                g = ops.instnorm_lrelu_bwd2(g, skip_g, ctx.raw[i], ctx.stats[i], LRELU)
+            g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0))
+            bk.mark_ready(grp); grp += 1
+
+    # ------------------------------------------------------------------------------------------------------------
+    # discriminator
+    # ------------------------------------------------------------------------------------------------------------
+    def d_forward(self, d_in: torch.Tensor):
+        """d_in [N,H,W,8] = [src | target-or-fake | 0 0] -> (logits [N,H/8-2,W/8-2,8] (channel 0), saved tensors)."""
+        c1, c2, c3, c4, c5 = self.d_layers
+        xs1 = ops.space_to_depth_pad1_t(d_in)
+        a1 = _conv_s2_fwd(c1, xs1, act=True, slope=LRELU)
+        xs2 = ops.space_to_depth_pad1_t(a1)
+        r2 = _conv_s2_fwd(c2, xs2)
+        a2 = torch.empty_like(r2)
+        s2 = ops.instnorm_lrelu_fwd2(r2, LRELU, a2)
+        xs3 = ops.space_to_depth_pad1_t(a2)
+        r3 = _conv_s2_fwd(c3, xs3)
+        a3 = torch.empty_like(r3)
+        s3 = ops.instnorm_lrelu_fwd2(r3, LRELU, a3)
+        r4 = ops.convkxk(a3, c4.wf, c4.bias.detach(), c4.conv_out, 4, 1)
+        a4 = torch.empty_like(r4)
+        s4 = ops.instnorm_lrelu_fwd2(r4, LRELU, a4)
+        z = ops.convkxk(a4, c5.wf, c5.bias.detach(), c5.conv_out, 4, 1)
+        return z, (xs1, a1, xs2, r2, s2, xs3, r3, s3, a3, r4, s4, a4)
+
+    def d_backward(self, saved, dz: torch.Tensor, want_w: bool, need_input_grad: bool):
+        """want_w: form the discriminator's weight gradients (D update) -- the generator update passes False and only
+        pulls the data gradient through the frozen discriminator.  Returns d(d_in) or None."""
+        c1, c2, c3, c4, c5 = self.d_layers
+        xs1, a1, xs2, r2, s2, xs3, r3, s3, a3, r4, s4, a4 = saved
+        gr, bk = self.pD.grads, self.pD.bucketer
+        if want_w:
+            bk.start_step()
+            ops.channel_sum_into(dz, gr["c5.bias"])
+        g = _conv_s1_bwd(c5, dz, a4, gr["c5.weight"], want_w)
+        if want_w:
+            bk.mark_ready(0)
+        g = ops.instnorm_lrelu_bwd2(g, None, r4, s4, LRELU)
+        g = _conv_s1_bwd(c4, g, a3, gr["c4.weight"], want_w)
+        if want_w:
+            bk.mark_ready(1)
+        g = ops.instnorm_lrelu_bwd2(g, None, r3, s3, LRELU)
+        g = _conv_s2_bwd(c3, g, xs3, gr["c3.weight"], True, want_w)
+        if want_w:
+            bk.mark_ready(2)
+        g = ops.instnorm_lrelu_bwd2(g, None, r2, s2, LRELU)
+        g = _conv_s2_bwd(c2, g, xs2, gr["c2.weight"], True, want_w)
+        if want_w:
+            bk.mark_ready(3)
+        g = ops.p2p_act_bwd(g, None, a1, LRELU, gr["c1.bias"] if want_w else None)
+        g = _conv_s2_bwd(c1, g, xs1, gr["c1.weight"], need_input_grad, want_w)
+        if want_w:
+            bk.mark_ready(4)
+        return g
+
+    # ------------------------------------------------------------------------------------------------------------
+    # the step
+    # ------------------------------------------------------------------------------------------------------------
+    def losses_and_grads(self, src: torch.Tensor, tgt: torch.Tensor, update: bool = True, want_fake: bool = False):
+        """One G + D evaluation.  ``update=True`` is the training step (D is updated before the generator's pass through
+        it, as in pix2pix_step); ``update=False`` leaves both networks untouched and evaluates the two losses and both
+        gradient sets at the CURRENT parameters (what ``(loss_D + loss_G).backward()`` of pix2pix_losses yields), for the
+        parity tests.  Returns (losses, fake): ``losses`` = device float[6] {BCE(D(real), 1), BCE(D(fake), 0),
+        BCE(D(fake), 1), 0, L1(fake, tgt), 0} (no host synchronisation; ``loss_values`` turns it into loss_D / loss_G),
+        ``fake`` = NCHW fp32 or None."""
+        B, C, H, W = tgt.shape
+        dev, dt = src.device, self.dtype
+        src, tgt = src.contiguous().float(), tgt.contiguous().float()
+        losses = torch.empty((6,), dtype=torch.float32, device=dev)
+        gctx = self.g_forward(src)
+        d_in = torch.empty((2 * B, H, W, 8), dtype=dt, device=dev)          # [real pairs | fake pairs]
+        ops.p2p_pack_input(src, tgt, d_in[:B])
+        fake = torch.empty((B, C, H, W), dtype=torch.float32, device=dev) if want_fake else None
+        ops.p2p_tanh_l1_fwd(gctx.h, src, tgt, d_in[B:], fake, l1_out=losses[4:5])
+        # ---- discriminator update: real and detached fake as one batch of 2B samples ----
+        z, saved = self.d_forward(d_in)
+        npatch = z.shape[1] * z.shape[2]
+        _, dz = ops.p2p_bce_logits(z, B, 0.5 / (B * npatch), 0.5 / (B * npatch), out=losses[0:2])
+        self.d_backward(saved, dz, want_w=True, need_input_grad=False)
+        if update:
+            self.pD.adam(self.lr, self.betas, self.eps, self.wd)
+            self.packD.repack()
+            zg, saved_g = self.d_forward(d_in[B:])                          # through the UPDATED discriminator
+        else:
+            self.pD.bucketer.wait_all()
+            zg, saved_g = z[B:], tuple(self._second_half(t, B) for t in saved)
+        # ---- generator update ----
+        _, dzg = ops.p2p_bce_logits(zg, B, 1.0 / (B * npatch), 0.0, out=losses[2:4])
+        gd = self.d_backward(saved_g, dzg, want_w=False, need_input_grad=True)
+        dh = ops.p2p_tanh_l1_bwd(gctx.h, tgt, gd, self.lambda_l1 / (B * C * H * W))
+        self.g_backward(gctx, dh)
+        if update:
+            self.pG.adam(self.lr, self.betas, self.eps, self.wd)
+            self.packG.repack()
+        else:
+            self.pG.bucketer.wait_all()
+        return losses, fake
+
+    @staticmethod
+    def _second_half(t: torch.Tensor, B: int) -> torch.Tensor:
+        # saved tensors are per-sample along dim 0, except the InstanceNorm statistics [4][N][C]
+        return t[:, B:].contiguous() if (t.dim() == 3 and t.shape[0] == 4) else t[B:]
+
+    def loss_values(self, losses: torch.Tensor) -> Tuple[float, float]:
+        """(loss_D, loss_G) = (0.5 (BCE_real + BCE_fake), BCE_gan + lambda L1) from a ``losses`` vector (one host read)."""
+        v = losses.detach().cpu().tolist()
+        return 0.5 * (v[0] + v[1]), v[2] + self.lambda_l1 * v[4]
+
+    def step(self, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        """One training step on this rank's shard of the global batch (the reference shards a batch as
+        ``batch_size // world_size`` per rank, src/data/paired_data_module.py:273-278); returns the ``losses`` vector
+        (rank means when ``sync_loss``), still on the device."""
+        losses, _ = self.losses_and_grads(src, tgt, update=True)
+        if self.sync_loss:
+            work = all_reduce_mean_scalar(losses, self.pg)
+            if work is not None:
+                work.wait()
+                ops.axpy_(losses, losses, 1.0 / dist.get_world_size(self.pg) - 1.0)     # x += (1/w - 1) x
+        return losses
+
+    @torch.no_grad()
+    def generate(self, src: torch.Tensor) -> torch.Tensor:
+        """fake = G(src) (training-mode statistics are the only ones InstanceNorm has), NCHW fp32."""
+        B, _, H, W = src.shape
+        src = src.contiguous().float()
+        ctx = self.g_forward(src)
+        d_in = torch.empty((B, H, W, 8), dtype=self.dtype, device=src.device)
+        fake = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=src.device)
+        zeros = torch.zeros_like(fake)
+        ops.p2p_tanh_l1_fwd(ctx.h, src[:, :self.out_channels].contiguous(), zeros, d_in, fake)
+        return fake

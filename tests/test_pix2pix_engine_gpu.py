@@ -1,0 +1,327 @@
+"""The fused pix2pix G + D step (stain2stain_amd.pix2pix_engine) and its kernels.
+
+Oracle: ``oracle/pix2pix_oracle.py`` -- the same two networks on torch's own layers, fp32 on the CPU, stepped with
+``stain2stain_amd.pix2pix.pix2pix_losses`` / ``pix2pix_step`` (plain torch code when handed torch modules) and
+``torch.optim.Adam``.  PARITY UNPINNED with respect to the reference repository, which has no pix2pix model
+(SURVEY.md F1); what is pinned here is agreement with torch's operators.
+
+Bounds: the fp32 mode (three-way bf16 split on the MFMA path) is held to the north-star 1e-3 (max-norm, relative per
+tensor) on the generator output, both losses and every gradient -- on a draw that is screened for ReLU / LeakyReLU /
+|.| knife edges exactly like the golden fixtures (the oracle must agree with itself to 2e-4 across fp32, fp64 and
+jittered fp64; see tests/golden/make_golden.py).  The bf16 throughput mode gets the bounds of a bf16 pipeline.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-3
+
+
+def _l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernels
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 24), (3, 8, 8, 64, 136), (1, 40, 32, 8, 64)])
+def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
+    """The three layer kinds in both dtypes: forward, data gradient and weight gradient against torch's conv on the CPU
+    (operands rounded to the storage dtype first, so the comparison sees the kernel and not the rounding of its inputs)."""
+    from stain2stain_amd import ops
+    B, H, W, cin, cout = shape
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    rnd = lambda *s: (torch.randn(*s, generator=g)).to(dtype).float()
+    x, w, b = rnd(B, cin, H, W), rnd(cout, cin, 4, 4) * 0.1, rnd(cout)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    nchw = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+    # --- stride 2 ---
+    wf, wd = ops.pack_conv4x4_t(w.to(DEV), 2, dtype)
+    xs = ops.space_to_depth_pad1_t(nhwc(x))
+    skip = torch.zeros((B, H // 2, W // 2, 2 * cout), dtype=dtype, device=DEV)
+    y = ops.convkxk(xs, wf, b.to(DEV), cout, 2, 0, act=True, slope=0.2, out2=skip[..., :cout])
+    ref = F.leaky_relu(F.conv2d(x, w, b, 2, 1), 0.2)
+    assert relerr(nchw(y), ref) < tol
+    assert relerr(nchw(skip[..., :cout]), torch.relu(ref)) < tol and float(skip[..., cout:].abs().max()) == 0
+    gy = rnd(B, cout, H // 2, W // 2)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, 2, 1).backward(gy)
+    dx = ops.depth_to_space_unpad1_t(ops.convkxk(nhwc(gy), wd, None, 4 * cin, 2, 1))
+    assert relerr(nchw(dx), xr.grad) < tol
+    gw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
+    ops.convkxk_wgrad(nhwc(gy), xs, gw, 2)
+    assert relerr(gw, wr.grad) < tol
+    # --- transposed, stride 2: weight [Cin][Cout][4][4], bias shared by the four sub-pixel groups ---
+    wt, bt = rnd(cin, cout, 4, 4) * 0.1, rnd(cout)
+    wf, wd = ops.pack_conv4x4_t(wt.to(DEV), 2, dtype)
+    yt = ops.depth_to_space_unpad1_t(ops.convkxk(nhwc(x), wd, bt.to(DEV), 4 * cout, 2, 1, bias_mod=cout))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, bt, 2, 1)
+    assert relerr(nchw(yt), ref) < tol
+    gy = rnd(B, cout, 2 * H, 2 * W)
+    ref.backward(gy)
+    gs = ops.space_to_depth_pad1_t(nhwc(gy))
+    assert relerr(nchw(ops.convkxk(gs, wf, None, cin, 2, 0)), xr.grad) < tol
+    gw = torch.empty((cin, cout, 4, 4), dtype=torch.float32, device=DEV)
+    ops.convkxk_wgrad(nhwc(x), gs, gw, 2)
+    assert relerr(gw, wr.grad) < tol
+    # --- stride 1 ---
+    wf, wd = ops.pack_conv4x4_t(w.to(DEV), 1, dtype)
+    y1 = ops.convkxk(nhwc(x), wf, b.to(DEV), cout, 4, 1)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, b, 1, 1)
+    assert relerr(nchw(y1), ref) < tol
+    gy = rnd(B, cout, H - 1, W - 1)
+    ref.backward(gy)
+    assert relerr(nchw(ops.convkxk(nhwc(gy), wd, None, cin, 4, 2)), xr.grad) < tol
+    gw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
+    ops.convkxk_wgrad(nhwc(gy), nhwc(x), gw, 4)
+    assert relerr(gw, wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_and_activation_kernels_against_torch(dtype):
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 3, 12, 20
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    src, tgt = torch.rand(B, 3, H, W, generator=g) * 2 - 1, torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    packed = ops.p2p_pack_input(src.to(DEV), tgt.to(DEV), torch.empty((B, H, W, 8), dtype=dtype, device=DEV))
+    want = torch.cat([src, tgt, torch.zeros(B, 2, H, W)], 1).permute(0, 2, 3, 1)
+    assert relerr(packed.float().cpu(), want.to(dtype).float()) == 0
+    # generator head: tanh + L1, forward and backward
+    h = (torch.randn(B, H, W, 8, generator=g)).to(dtype)
+    d_in = torch.empty((B, H, W, 8), dtype=dtype, device=DEV)
+    fake = torch.empty((B, 3, H, W), dtype=torch.float32, device=DEV)
+    l1 = ops.p2p_tanh_l1_fwd(h.to(DEV), src.to(DEV), tgt.to(DEV), d_in, fake)
+    hr = h.float()[..., :3].permute(0, 3, 1, 2).clone().requires_grad_(True)
+    fr = torch.tanh(hr)
+    assert relerr(fake, fr) < 1e-6 and relerr(l1[0], (fr - tgt).abs().mean()) < 1e-6
+    assert relerr(d_in.float().cpu()[..., 3:6].permute(0, 3, 1, 2), fr.to(dtype).float()) < tol
+    assert float(d_in[..., 6:].abs().max()) == 0 and relerr(d_in.float().cpu()[..., :3].permute(0, 3, 1, 2), src.to(dtype).float()) == 0
+    gd = torch.randn(B, H, W, 8, generator=g).to(dtype)
+    lam = 100.0
+    (lam * (fr - tgt).abs().mean() + (fr * gd.float()[..., 3:6].permute(0, 3, 1, 2)).sum()).backward()
+    dh = ops.p2p_tanh_l1_bwd(h.to(DEV), tgt.to(DEV), gd.to(DEV), lam / (B * 3 * H * W))
+    assert relerr(dh.float().cpu()[..., :3].permute(0, 3, 1, 2), hr.grad) < tol and float(dh[..., 3:].abs().max()) == 0
+    # PatchGAN BCE: first n_real samples against ones, the rest against zeros
+    z = (torch.randn(4, 5, 6, 8, generator=g) * 3).to(dtype)
+    zr = z.float()[..., 0].clone().requires_grad_(True)
+    bce = F.binary_cross_entropy_with_logits
+    lr_, lf_ = bce(zr[:1], torch.ones(1, 5, 6)), bce(zr[1:], torch.zeros(3, 5, 6))
+    (0.25 * lr_ + 0.75 * lf_).backward()
+    out, dz = ops.p2p_bce_logits(z.to(DEV), 1, 0.25 / 30, 0.75 / 90)
+    assert relerr(out[0], lr_) < 1e-6 and relerr(out[1], lf_) < 1e-6
+    assert relerr(dz.float().cpu()[..., 0], zr.grad) < tol and float(dz[..., 1:].abs().max()) == 0
+    # activation backward (mask from the stored output) + bias gradient
+    a = F.leaky_relu(torch.randn(2, 6, 10, 24, generator=g), 0.2).to(dtype)
+    g1, g2 = torch.randn(2, 6, 10, 24, generator=g).to(dtype), torch.randn(2, 6, 10, 48, generator=g).to(dtype)
+    db = torch.empty(24, dtype=torch.float32, device=DEV)
+    dzz = ops.p2p_act_bwd(g1.to(DEV), g2.to(DEV)[..., :24], a.to(DEV), 0.2, db)
+    want = torch.where(a.float() > 0, g1.float() + g2.float()[..., :24], 0.2 * g1.float())
+    assert relerr(dzz.float().cpu(), want.to(dtype).float()) < tol
+    assert relerr(db, want.sum((0, 1, 2))) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_instnorm_second_output_and_second_gradient():
+    """InstanceNorm + LeakyReLU with the ReLU'd skip copy written into a wider buffer, and its backward with the gradient
+    arriving on both outputs, against torch autograd (fp32)."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, H, W, C = 3, 10, 12, 40
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty((B, H, W, C), device=DEV)
+    cat = torch.zeros((B, H, W, 2 * C), device=DEV)
+    st = ops.instnorm_lrelu_fwd2(xn, 0.2, y, cat[..., :C])
+    xr = x.clone().requires_grad_(True)
+    zn = F.instance_norm(xr)
+    ya, yb = F.leaky_relu(zn, 0.2), torch.relu(zn)
+    assert relerr(y.cpu().permute(0, 3, 1, 2), ya) < 1e-5 and relerr(cat.cpu()[..., :C].permute(0, 3, 1, 2), yb) < 1e-5
+    assert float(cat[..., C:].abs().max()) == 0
+    ga, gb = torch.randn(B, C, H, W, generator=g), torch.randn(B, 2 * C, H, W, generator=g)
+    (ya * ga).sum().backward(retain_graph=True)
+    (yb * gb[:, :C]).sum().backward()
+    dx = ops.instnorm_lrelu_bwd2(ga.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                 gb.permute(0, 2, 3, 1).contiguous().to(DEV)[..., :C], xn, st, 0.2)
+    assert relerr(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the two networks and the step
+# ----------------------------------------------------------------------------------------------------------------------
+def _build(ngf, ndf, num_downs, seed, bf16_weights):
+    from oracle import pix2pix_oracle as O
+    from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator
+    torch.manual_seed(seed)
+    G, D = Pix2PixGenerator(ngf=ngf, num_downs=num_downs), PatchGANDiscriminator(ndf=ndf)
+    rb = (lambda t: t.to(torch.bfloat16).float()) if bf16_weights else (lambda t: t.clone())
+    sd_g, sd_d = {k: rb(v) for k, v in G.state_dict().items()}, {k: rb(v) for k, v in D.state_dict().items()}
+    G.load_state_dict(sd_g); D.load_state_dict(sd_d)
+    Go, Do = O.OracleGenerator(ngf=ngf, num_downs=num_downs), O.OracleDiscriminator(ndf=ndf)
+    Go.load_state_dict(sd_g); Do.load_state_dict(sd_d)
+    return G.to(DEV), D.to(DEV), Go, Do
+
+
+def _oracle_eval(Go, Do, src, tgt, dtype=torch.float32):
+    """fake, loss_D, loss_G and all gradients of the oracle at its current parameters (pix2pix_losses is plain torch)."""
+    from stain2stain_amd.pix2pix import pix2pix_losses
+    Go, Do = Go.to(dtype), Do.to(dtype)
+    fake, ld, lg = pix2pix_losses(Go, Do, src.to(dtype), tgt.to(dtype))
+    # what the G + D step uses: the discriminator is updated on loss_D alone (the generator's pass through it leaves its
+    # weights frozen), the generator on loss_G
+    gg = torch.autograd.grad(lg, list(Go.parameters()), retain_graph=True)
+    gd = torch.autograd.grad(ld, list(Do.parameters()))
+    grads = {"G." + k: v.double() for (k, _), v in zip(Go.named_parameters(), gg)}
+    grads.update({"D." + k: v.double() for (k, _), v in zip(Do.named_parameters(), gd)})
+    Go.float(); Do.float()
+    return fake.detach().double(), float(ld.detach()), float(lg.detach()), grads
+
+
+def _screened_batch(Go, Do, shape, first_seed):
+    """First data seed on which the oracle's own gradients agree to 2e-4 across fp32, fp64 and 3e-7-jittered fp64."""
+    for seed in range(first_seed, first_seed + 60):
+        g = torch.Generator().manual_seed(seed)
+        src, tgt = torch.rand(*shape, generator=g) * 2 - 1, torch.rand(*shape, generator=g) * 2 - 1
+        ref = _oracle_eval(Go, Do, src, tgt, torch.float64)[3]
+        scale = max(float(v.abs().max()) for v in ref.values())
+        worst = 0.0
+        runs = [_oracle_eval(Go, Do, src, tgt)[3]]
+        for j in (1, 2):
+            gj = torch.Generator().manual_seed(j)
+            jit = lambda t: t.double() + 3e-7 * torch.randn(t.shape, generator=gj, dtype=torch.float64)
+            runs.append(_oracle_eval(Go, Do, jit(src), jit(tgt), torch.float64)[3])
+        for other in runs:
+            worst = max(worst, max(float((other[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale)
+                                   for k in ref))
+        print(f"  data seed {seed}: oracle gradients under fp32 / fp64 / jitter move by {worst:.2e}")
+        if worst < 2e-4:
+            return src, tgt
+    raise RuntimeError("no well-conditioned draw found")
+
+
+def _engine_grads(tr):
+    out = {"G." + k: p.grad.detach().double().cpu() for k, p in tr.G.named_parameters()}
+    out.update({"D." + k: p.grad.detach().double().cpu() for k, p in tr.D.named_parameters()})
+    return out
+
+
+def test_fp32_mode_matches_the_oracle_to_1e3():
+    """Generator output, both losses and every parameter gradient of G and D at 1e-3 on a screened draw."""
+    from stain2stain_amd import Pix2PixTrainer
+    G, D, Go, Do = _build(16, 16, 5, 1984, bf16_weights=False)
+    src, tgt = _screened_batch(Go, Do, (2, 3, 64, 64), 1984)
+    fake_o, ld_o, lg_o, gref = _oracle_eval(Go, Do, src, tgt, torch.float64)
+    tr = Pix2PixTrainer(G, D, precision="fp32")
+    losses, fake = tr.losses_and_grads(src.to(DEV), tgt.to(DEV), update=False, want_fake=True)
+    ld, lg = tr.loss_values(losses)
+    print(f"fp32 mode: fake {relerr(fake, fake_o):.2e}, loss_D {ld:.6f} vs {ld_o:.6f}, loss_G {lg:.5f} vs {lg_o:.5f}")
+    assert relerr(fake, fake_o) < TOL
+    assert abs(ld - ld_o) < TOL * abs(ld_o) and abs(lg - lg_o) < TOL * abs(lg_o)
+    got = _engine_grads(tr)
+    scale_g = max(float(v.abs().max()) for k, v in gref.items() if k.startswith("G."))
+    scale_d = max(float(v.abs().max()) for k, v in gref.items() if k.startswith("D."))
+    worst = 0.0
+    for k, r in gref.items():
+        scale = scale_g if k.startswith("G.") else scale_d
+        # a conv bias ahead of InstanceNorm has an analytically zero gradient (noise in torch, exact 0 here):
+        # such tensors are compared on the scale of their network's whole gradient
+        bound = TOL * max(float(r.abs().max()), 1e-3 * scale)
+        err = float((got[k] - r).abs().max())
+        worst = max(worst, err / max(float(r.abs().max()), 1e-3 * scale))
+        assert err <= bound, (k, err, bound)
+    print(f"fp32 mode: worst gradient error {worst:.2e} (bound {TOL})")
+
+
+def test_bf16_mode_tracks_the_oracle():
+    """Throughput mode (bf16 storage): generator output in L2, losses to a fraction of a per cent, gradient directions."""
+    from stain2stain_amd import Pix2PixTrainer
+    G, D, Go, Do = _build(16, 16, 6, 1984, bf16_weights=True)
+    g = torch.Generator().manual_seed(7)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    src, tgt = rb(torch.rand(4, 3, 64, 64, generator=g) * 2 - 1), rb(torch.rand(4, 3, 64, 64, generator=g) * 2 - 1)
+    fake_o, ld_o, lg_o, gref = _oracle_eval(Go, Do, src, tgt)
+    tr = Pix2PixTrainer(G, D, precision="bf16")
+    losses, fake = tr.losses_and_grads(src.to(DEV), tgt.to(DEV), update=False, want_fake=True)
+    ld, lg = tr.loss_values(losses)
+    print(f"bf16 mode: fake rel-L2 {_l2(fake, fake_o):.2e}, loss_D {ld:.5f} vs {ld_o:.5f}, loss_G {lg:.4f} vs {lg_o:.4f}")
+    assert _l2(fake, fake_o) < 3e-2
+    assert abs(ld - ld_o) < 5e-3 * abs(ld_o) and abs(lg - lg_o) < 5e-3 * abs(lg_o)
+    got = _engine_grads(tr)
+    scale = max(float(v.norm()) for v in gref.values())
+    worst = 1.0
+    for k, r in gref.items():
+        if float(r.norm()) < 1e-4 * scale:
+            continue
+        cos = float((got[k] * r).sum() / (got[k].norm() * r.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.95, (k, cos)
+    print(f"bf16 mode: smallest gradient cosine {worst:.4f}")
+
+
+def test_training_steps_follow_the_oracle_adam_loop():
+    """Three full G + D steps in fp32 mode (D updated before the generator's pass through it, Adam(2e-4, 0.5/0.999) on
+    both networks) against pix2pix_step over the oracle networks with torch.optim.Adam: losses step by step and the
+    parameters afterwards."""
+    from stain2stain_amd import Pix2PixTrainer
+    from stain2stain_amd.pix2pix import pix2pix_step
+    G, D, Go, Do = _build(16, 16, 5, 7, bf16_weights=False)
+    g = torch.Generator().manual_seed(70)
+    batches = [(torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1)
+               for _ in range(3)]
+    tr = Pix2PixTrainer(G, D, lr=2e-4, betas=(0.5, 0.999), precision="fp32")
+    og = torch.optim.Adam(Go.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(Do.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    for s, (src, tgt) in enumerate(batches):
+        ld, lg = tr.loss_values(tr.step(src.to(DEV), tgt.to(DEV)))
+        ld_o, lg_o = (float(v) for v in pix2pix_step(Go, Do, og, od, src, tgt))
+        print(f"step {s}: loss_D {ld:.6f} vs {ld_o:.6f}, loss_G {lg:.5f} vs {lg_o:.5f}")
+        assert abs(ld - ld_o) < 2e-3 * abs(ld_o) and abs(lg - lg_o) < 2e-3 * abs(lg_o)
+    # after three Adam steps every weight has moved by ~3 lr; the two runs may differ by a fraction of that where a
+    # gradient's sign is in the noise (Adam normalises), so: tight on the bulk, lr-scaled bound on the worst element
+    # (a conv bias ahead of InstanceNorm has no effect and an analytically zero gradient: exactly 0 here, rounding noise
+    # in torch, which Adam's normalisation turns into +-lr random steps -- those biases are not comparable and are skipped)
+    n = len(G.downs)
+    normed = {f"downs.{i}.bias" for i in range(1, n - 1)} | {f"ups.{j}.bias" for j in range(n - 1)} | {"c2.bias", "c3.bias", "c4.bias"}
+    for mod, ref in ((G, Go), (D, Do)):
+        for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+            if k in normed:
+                continue
+            d = (p.detach().cpu() - q.detach()).abs()
+            assert float(d.max()) <= 2 * 3 * 2e-4 + 1e-3 * float(q.abs().max()), (k, float(d.max()))
+            assert float(d.mean()) <= 0.15 * 3 * 2e-4, (k, float(d.mean()))
+
+
+def test_headline_networks_fp32_forward_and_discriminator():
+    """The bench configuration's networks (8-level generator ngf = 64, PatchGAN ndf = 64) at 256x256, batch 2, fp32 mode:
+    generator output and discriminator logits against the oracle at 1e-3."""
+    from oracle import pix2pix_oracle as O
+    from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator, Pix2PixTrainer, ops
+    torch.manual_seed(1984)
+    G, D = Pix2PixGenerator(), PatchGANDiscriminator()
+    Go, Do = O.OracleGenerator(), O.OracleDiscriminator()
+    Go.load_state_dict(G.state_dict()); Do.load_state_dict(D.state_dict())
+    g = torch.Generator().manual_seed(11)
+    src, tgt = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1, torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    tr = Pix2PixTrainer(G.to(DEV), D.to(DEV), precision="fp32")
+    fake = tr.generate(src.to(DEV))
+    d_in = ops.p2p_pack_input(src.to(DEV), tgt.to(DEV), torch.empty((2, 256, 256, 8), device=DEV))
+    z, _ = tr.d_forward(d_in)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    try:
+        with torch.no_grad():
+            fake_o, z_o = Go(src), Do(src, tgt)
+    finally:
+        torch.set_num_threads(threads)
+    print(f"headline fp32: G output {relerr(fake, fake_o):.2e}, D logits {relerr(z[..., 0].cpu(), z_o[:, 0]):.2e}")
+    assert fake.shape == (2, 3, 256, 256) and z.shape == (2, 30, 30, 8)
+    assert relerr(fake, fake_o) < TOL and relerr(z[..., 0].cpu(), z_o[:, 0]) < TOL
