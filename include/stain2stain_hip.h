@@ -274,8 +274,12 @@ int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const 
  * transposed layers, whose four sub-pixel channel groups share the layer's bias vector.  stat_part (optional): float[2][Cout][s2s_convkxk_stat_blocks()]. */
 int s2s_convkxk_stat_blocks(int dtype, int B, int H, int W, int Cout, int ks);
 int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias, int bias_mod,
-                     void* y, int ldy, void* y2, int ldy2, int act, float act_slope, float* stat_part, int B, int H, int W,
-                     int Cout, int ks, int pad, void* stream);
+                     void* y, int ldy, void* y2, int ldy2, int act, float act_slope, float* stat_part, float* kwork, int B,
+                     int H, int W, int Cout, int ks, int pad, void* stream);
+/* Split-K for the small maps of the inner U-Net levels: with kwork = float[s2s_convkxk_ksplit()][B*H*W][Cout] (optional,
+ * bf16 only) that many workgroups share an output tile, each reducing a range of the input-channel chunks, and a
+ * second launch folds the fp32 partial tiles (+ bias, activation).  Returns 1 when the launch is not split. */
+int s2s_convkxk_ksplit(int dtype, int B, int H, int W, int Cout, int cin, int ks);
 /* Weight gradient of the pad-0 (ks = 2) / pad-1 (ks = 4) forms: dY [B][H][W][Cout], X [B][H+1][W+1][cin].
  * layout 0: grad[ks*ks][Cout][cin]; layout 1: nn.Conv2d's [Cout][C][4][4] (ks = 2: cin = 4 C over the space-to-depth
  * channels; with the roles of a transposed layer's input and output gradient exchanged the same call yields

@@ -52,6 +52,11 @@ struct Conv3x3Args {
   float act_slope;
   void* y2;
   int ldy2;
+  // split-K (convkxk_dma16_kernel only): gridDim.z workgroups share one output tile, each reduces a contiguous range
+  // of the 32-channel chunks and writes its fp32 partial tile to kpart[z][B*H*W][Cout]; convk_splitk_reduce_kernel
+  // adds them up and applies bias / activation.  nullptr = one workgroup per tile, epilogue in the kernel.
+  float* kpart;
+  int ksplit;
   int bias_mod;   // bias index = channel % bias_mod (= Cout normally; Cout / 4 for the transposed 4x4 layers, whose four
                   // sub-pixel channel groups share one bias vector)
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
@@ -982,6 +987,8 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   const int y0 = ty * TH, x0p = tx * TW;
   const int n0 = blockIdx.y * BN;
   const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;
+  // this workgroup's chunk range [c_lo, c_hi): all of them, or the blockIdx.z-th share of a split-K launch
+  const int c_lo = (int)(((long)blockIdx.z * a.nchunk) / gridDim.z), c_hi = (int)(((long)(blockIdx.z + 1) * a.nchunk) / gridDim.z);
 
   const int drow = lane >> 2, dslot = lane & 3;
   int apix[HG], apc[HG];
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   for (int j = 0; j < BG; ++j) {
     const int n = (wave + 4 * j) * 16 + drow;
     const bool ok = n0 + n < a.Cout;
-    wptr[j] = ok ? wp + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
+    wptr[j] = ok ? wp + (long)c_lo * TAPS * a.Cout * 64 + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
     wstep[j] = ok ? a.Cout * 64 : 0;
   }
   auto dma_halo = [&](int c) {
@@ -1054,13 +1061,13 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
       for (int ni = 0; ni < NI; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   };
-  dma_halo(0);
-  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // nchunk * TAPS >= 3 slabs always exist
+  dma_halo(c_lo);
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // (c_hi - c_lo) * TAPS >= 3 slabs always exist
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  int c = 0;
-  for (; c + 1 < a.nchunk; ++c) {
+  int c = c_lo;
+  for (; c + 1 < c_hi; ++c) {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
     const int it0 = c * TAPS;
     static_for<TAPS>([&](auto tapc) {
@@ -1093,6 +1100,26 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_s_barrier();
     });
   }
+  if (a.kpart) {
+    // split-K: the fp32 partial tile straight from the accumulators (a lane's four registers = four consecutive
+    // channels of one pixel: one 16-byte store)
+    float* const kpz = a.kpart + (long)blockIdx.z * ((long)a.B * a.H * a.W) * a.Cout;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = wm * WTM + mi * 16 + cl;
+      const int py = m / TW, px = m - py * TW;
+      const int gy = y0 + py, gx = x0p + px;
+      if (gy < a.H && gx < a.W) {
+        float* const row = kpz + (((long)img * a.H + gy) * a.W + gx) * a.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = n0 + wn * WTN + ni * 16 + 4 * kp;
+          if (n < a.Cout) *reinterpret_cast<f32x4*>(row + n) = acc[mi][ni];
+        }
+      }
+    }
+    return;
+  }
   if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
 }
@@ -1109,10 +1136,37 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
-  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.kpart ? a.ksplit : 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+// out[p][n] = act(sum_z kpart[z][p][n] + bias[n % bias_mod]) for the split-K launches; 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void convk_splitk_reduce_kernel(Conv3x3Args a, long npix) {
+  const int cp = a.Cout >> 3;
+  const long total = npix * cp, slab = npix * a.Cout;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cp;
+    const int n = (int)(i - p * cp) * 8;
+    f32x8 acc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc.v[k] = a.bias ? a.bias[(n + k) % a.bias_mod] : 0.f;
+    for (int z = 0; z < a.ksplit; ++z) {
+      const f32x8 v = load8(a.kpart + (long)z * slab + p * a.Cout + n);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc.v[k] += v.v[k];
+    }
+    f32x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (a.act) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : a.act_slope * acc.v[k];
+      r.v[k] = fmaxf(acc.v[k], 0.f);
+    }
+    store8(static_cast<T*>(a.y) + p * a.ldy + n, acc);
+    if (a.y2) store8(static_cast<T*>(a.y2) + p * a.ldy2 + n, r);
+  }
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
@@ -1422,7 +1476,7 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
@@ -1450,9 +1504,28 @@ extern "C" int s2s_convkxk_stat_blocks(int dtype, int B, int H, int W, int Cout,
   return W > 16 ? B * cdiv(H, 4) * cdiv(W, 32) : B * cdiv(H, 8) * cdiv(W, 16);
 }
 
+// Number of K splits s2s_convkxk_nhwc uses when it is handed a workspace (bf16 only): the inner levels of the pix2pix
+// generator have 16 ... 64 output tiles, each reducing over K = 16 x 512 ... 1024 -- a few dozen workgroups streaming
+// 8 ... 16 MB of weights for tens of microseconds.  Splitting the chunk range brings the launch to ~512 workgroups.
+// kwork: float[splits][B*H*W][Cout].
+extern "C" int s2s_convkxk_ksplit(int dtype, int B, int H, int W, int Cout, int cin, int ks) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (ks != 2 && ks != 4)) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16) return 1;
+  const bool wide = W > 16, big = Cout > 64;
+  const int th = (ks == 4 && wide) ? 4 : 8, tw = wide ? 32 : 16, bn = big ? 128 : 64;
+  const long base = (long)B * cdiv(H, th) * cdiv(W, tw) * cdiv(Cout, bn);
+  const int nchunk = cdiv(cin, 32);
+  if (base >= 192 || nchunk < 8) return 1;
+  long sp = (512 + base - 1) / base;
+  if (sp > nchunk / 4) sp = nchunk / 4;               // at least four chunks (16 or 64 taps) per workgroup
+  if (sp > 32) sp = 32;
+  return sp < 2 ? 1 : (int)sp;
+}
+
 extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
                                 int bias_mod, void* y, int ldy, void* y2, int ldy2, int act, float act_slope,
-                                float* stat_part, int B, int H, int W, int Cout, int ks, int pad, void* stream) {
+                                float* stat_part, float* kwork, int B, int H, int W, int Cout, int ks, int pad,
+                                void* stream) {
   if (!x || !w_packed || !y) return S2S_ERR_NULL;
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (cin % 8) || (ldx % 8) || (Cout % 8) || (ldy % 8) || ldy < Cout) return S2S_ERR_SHAPE;
@@ -1466,6 +1539,9 @@ extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, cons
   a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
   a.bias_mod = bias_mod > 0 ? bias_mod : Cout;
+  a.ksplit = kwork ? s2s_convkxk_ksplit(dtype, B, H, W, Cout, cin, ks) : 1;
+  a.kpart = a.ksplit > 1 ? kwork : nullptr;
+  if (a.kpart && stat_part) return S2S_ERR_SHAPE;                   // split launches do not produce statistics
   a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
   a.tilesX = a.tilesY = 0;
@@ -1480,20 +1556,31 @@ extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, cons
       default: return wide ? launch_cfg<float, 4, 32, 64, 2, 2, 4, 2>(a, s) : launch_cfg<float, 8, 16, 64, 2, 2, 4, 2>(a, s);
     }
   }
+  int rc;
   switch (form) {
     case 8:
-      if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0>(a, s);
-      return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0>(a, s);
+      if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0>(a, s);
+      else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0>(a, s);
+      break;
     case 9:
-      if (wide) return big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1>(a, s);
-      return big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1>(a, s);
+      if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1>(a, s);
+      else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1>(a, s);
+      break;
     case 17:      // 4-row tiles on wide maps: two workgroups per CU with the 7-row halo
-      if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 1>(a, s);
-      return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 1>(a, s);
+      if (wide) rc = big ? launch_convkxk<4, 32, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 1>(a, s);
+      else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 4, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 1>(a, s);
+      break;
     default:
-      if (wide) return big ? launch_convkxk<4, 32, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 2>(a, s);
-      return big ? launch_convkxk<8, 16, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 2>(a, s);
+      if (wide) rc = big ? launch_convkxk<4, 32, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<4, 32, 64, 2, 2, 4, 2>(a, s);
+      else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 4, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 4, 2>(a, s);
   }
+  if (rc != S2S_OK || !a.kpart) return rc;
+  const long npix = (long)B * H * W, pieces = npix * (Cout / 8);
+  long nb = (pieces + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(convk_splitk_reduce_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, npix);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }
 
 // the two entry points of round 1, kept for their callers: s2s_convkxk_nhwc without activation / second output
@@ -1505,14 +1592,14 @@ extern "C" int s2s_conv2x2_nhwc(int dtype, const void* x, int ldx, int cin, cons
                                 void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
                                 void* stream) {
   if (pad != 0 && pad != 1) return S2S_ERR_SHAPE;
-  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, B, H, W, Cout, 2, pad,
-                          stream);
+  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, nullptr, B, H, W, Cout,
+                          2, pad, stream);
 }
 
 extern "C" int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, const void* w_packed, const float* bias,
                                   void* y, int ldy, float* stat_part, int B, int H, int W, int Cout, int pad,
                                   void* stream) {
   if (pad != 1 && pad != 2) return S2S_ERR_SHAPE;
-  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, B, H, W, Cout, 4, pad,
-                          stream);
+  return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, nullptr, B, H, W, Cout,
+                          4, pad, stream);
 }

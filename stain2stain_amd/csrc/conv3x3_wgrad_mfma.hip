@@ -882,11 +882,14 @@ __global__ __launch_bounds__(256, (std::is_same<T, float>::value ? 1 : 2)) void 
 //   mode 2 (stride-1 layers, slabs [16 taps (kh,kw)][Cout][C]):  grad[o][c][kh][kw] (+)= sum_z part[z][kh*4+kw][o][c]
 // A workgroup owns one o and 64 consecutive c: its four waves read the sixteen 256-byte rows of every slab, the sums
 // meet in LDS and leave as 1024 contiguous floats.
-__global__ __launch_bounds__(256) void wgrad_fold4x4_kernel(const float* __restrict__ part, float* __restrict__ grad, int S,
-                                                            int Cout, int C, int mode, int accumulate) {
-  __shared__ float tile[16][65];
+template <int ZG>
+__global__ __launch_bounds__(256 * ZG) void wgrad_fold4x4_kernel(const float* __restrict__ part, float* __restrict__ grad, int S,
+                                                                 int Cout, int C, int mode, int accumulate) {
+  // ZG groups of four waves take every ZG-th slab (a layer with few (o, c) tiles has up to 256 slabs to fold, so the
+  // parallelism has to come from inside the workgroup); eight loads in flight per thread
+  __shared__ float tile[ZG][16][65];
   const int o = blockIdx.y, c0 = blockIdx.x * 64;
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 63, grp = (threadIdx.x >> 6) & 3, zg = threadIdx.x >> 8;
   const long slab = 16L * Cout * C;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -894,22 +897,27 @@ __global__ __launch_bounds__(256) void wgrad_fold4x4_kernel(const float* __restr
     long src;
     if (mode == 1) src = ((long)((kh >> 1) * 2 + (kw >> 1)) * Cout + o) * (4L * C) + ((kh & 1) * 2 + (kw & 1)) * C + c0 + cl;
     else src = ((long)t16 * Cout + o) * C + c0 + cl;
-    float s0 = 0.f, s1 = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
     if (c0 + cl < C) {
-      int z = 0;
-      for (; z + 1 < S; z += 2) { s0 += part[(long)z * slab + src]; s1 += part[(long)(z + 1) * slab + src]; }
-      if (z < S) s0 += part[(long)z * slab + src];
+      int z = zg;
+      for (; z + 7 * ZG < S; z += 8 * ZG) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += part[(long)(z + k * ZG) * slab + src];
+      }
+      for (; z < S; z += ZG) acc[0] += part[(long)z * slab + src];
     }
-    tile[t16][cl] = s0 + s1;
+    tile[zg][t16][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   __syncthreads();
   const long base = ((long)o * C + c0) * 16;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = threadIdx.x + i * 256;
+  for (int k = threadIdx.x; k < 1024; k += 256 * ZG) {
     const int c = k >> 4, t16 = k & 15;
     if (c0 + c < C) {
-      const float v = tile[t16][c];
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < ZG; ++g) v += tile[g][t16][c];
       grad[base + k] = accumulate ? grad[base + k] + v : v;
     }
   }
@@ -1158,8 +1166,12 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
     hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad, a.S, n, accumulate);
   } else {
     const int C = ks == 2 ? cin / 4 : cin;
-    hipLaunchKernelGGL(wgrad_fold4x4_kernel, dim3(cdiv(C, 64), Cout), dim3(256), 0, s, part, grad, a.S, Cout, C,
-                       ks == 2 ? 1 : 2, accumulate);
+    if (a.S >= 16 && (long)cdiv(C, 64) * Cout <= 1024)
+      hipLaunchKernelGGL(wgrad_fold4x4_kernel<4>, dim3(cdiv(C, 64), Cout), dim3(1024), 0, s, part, grad, a.S, Cout, C,
+                         ks == 2 ? 1 : 2, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_fold4x4_kernel<1>, dim3(cdiv(C, 64), Cout), dim3(256), 0, s, part, grad, a.S, Cout, C,
+                         ks == 2 ? 1 : 2, accumulate);
   }
   S2S_LAUNCH_CHECK();
   return S2S_OK;

@@ -433,22 +433,75 @@ __global__ __launch_bounds__(256) void pack4x4_kernel(const float* __restrict__ 
 }
 
 // every 4x4 layer of a network in one launch (after the fused Adam step): desc[l] = {w, wf, wd, Cout, Cin, stride2,
-// first block}; a workgroup handles 2048 consecutive elements of its layer's packed pair
-__global__ __launch_bounds__(256) void pack4x4_batched_kernel(const long* __restrict__ desc, int nlayers, int dtype) {
+// first block}.  Layers whose channel counts are multiples of 32 go through an LDS tile: a workgroup owns a 32 (o) x
+// 32 (c) block of the master (each o row is 2 KiB contiguous), holds it as tile[tap][o][c] and writes both operands
+// as 16-byte (bf16) pieces -- the element-wise form reads 4 bytes out of every 64-byte line it touches.  The few
+// 8-channel layers (image side) keep the element-wise form, 2048 elements per workgroup.
+__host__ __device__ inline long pack4x4_layer_blocks(int Cout, int Cin, int stride2) {
+  if ((Cout % 32) == 0 && (Cin % 32) == 0) return (long)(Cout / 32) * (Cin / 32);
+  const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
+  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+  return (n + 2047) / 2048;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack4x4_batched_kernel(const long* __restrict__ desc, int nlayers) {
   int l = 0;
   while (l + 1 < nlayers && (long)blockIdx.x >= desc[(l + 1) * 7 + 6]) ++l;
   const long* d = desc + l * 7;
-  const float* w = reinterpret_cast<const float*>(d[0]);
+  const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
+  T* __restrict__ wf = reinterpret_cast<T*>(d[1]);
+  T* __restrict__ wd = reinterpret_cast<T*>(d[2]);
   const int Cout = (int)d[3], Cin = (int)d[4], stride2 = (int)d[5];
+  const int blk = (int)((long)blockIdx.x - d[6]);
   const int taps = stride2 ? 4 : 16, K = stride2 ? 4 * Cin : Cin;
-  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
-  const long e0 = ((long)blockIdx.x - d[6]) * 2048;
+  if ((Cout % 32) || (Cin % 32)) {
+    const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
+    const long e0 = (long)blk * 2048;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long e = e0 + i * 256 + threadIdx.x;
-    if (e < n) {
-      if (dtype == S2S_BF16) pack4x4_elem<bf16_t>(w, reinterpret_cast<bf16_t*>(d[1]), reinterpret_cast<bf16_t*>(d[2]), Cout, Cin, stride2, e);
-      else pack4x4_elem<float>(w, reinterpret_cast<float*>(d[1]), reinterpret_cast<float*>(d[2]), Cout, Cin, stride2, e);
+    for (int i = 0; i < 8; ++i) {
+      const long e = e0 + i * 256 + threadIdx.x;
+      if (e < n) pack4x4_elem<T>(w, wf, wd, Cout, Cin, stride2, e);
+    }
+    return;
+  }
+  constexpr int PL = 32 * 33 + 1;                       // plane stride: 1 (mod 32), so the 8 taps a thread scatters hit 8 banks
+  __shared__ float tile[8 * PL];
+  const int cb = Cin / 32, o0 = (blk / cb) * 32, c0 = (blk % cb) * 32;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {                 // kernel rows kh = 2 pass, 2 pass + 1 (8 of the 16 taps)
+    if (pass) __syncthreads();
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+      const int c = idx & 31, o = idx >> 5;
+      const float* src = w + ((long)(o0 + o) * Cin + c0 + c) * 16 + pass * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { tile[t * PL + o * 33 + c] = a[t]; tile[(4 + t) * PL + o * 33 + c] = b[t]; }
+    }
+    __syncthreads();
+    // 8 taps x 32 rows x 4 pieces of 8 = 1024 pieces per operand
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+      const int k8 = (idx & 3) * 8, row = (idx >> 2) & 31, t8 = idx >> 7;
+      const int kh = pass * 2 + (t8 >> 2), kw = t8 & 3;
+      long fdst, ddst;
+      if (stride2) {
+        const int ab = (kh >> 1) * 2 + (kw >> 1), rs = (kh & 1) * 2 + (kw & 1);
+        const int k0 = rs * Cin + c0;                                  // a multiple of 32
+        fdst = (((long)(k0 >> 5) * 4 + ab) * Cout + o0 + row) * 32 + k8;             // wf[chunk][tap][o][kk = c]
+        ddst = (((long)(o0 >> 5) * 4 + (3 - ab)) * K + k0 + row) * 32 + k8;          // wd[o chunk][flipped tap][k][oo]
+      } else {
+        const int t16 = kh * 4 + kw;
+        fdst = (((long)(c0 >> 5) * 16 + t16) * Cout + o0 + row) * 32 + k8;
+        ddst = (((long)(o0 >> 5) * 16 + (15 - t16)) * K + c0 + row) * 32 + k8;
+      }
+      f32x8 vf, vd;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        vf.v[i] = tile[t8 * PL + row * 33 + k8 + i];                   // o = row, c = k8 + i
+        vd.v[i] = tile[t8 * PL + (k8 + i) * 33 + row];                 // c = row, o = k8 + i
+      }
+      store8(wf + fdst, vf);
+      store8(wd + ddst, vd);
     }
   }
 }
@@ -482,18 +535,20 @@ extern "C" int s2s_pack_conv4x4_t(int dtype, const float* w_oihw, void* wf, void
 // blocks a layer occupies in the batched launch (the caller accumulates them into desc[l][6])
 extern "C" long s2s_pack_conv4x4_blocks(int Cout, int Cin, int stride) {
   if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2)) return S2S_ERR_SHAPE;
-  const int taps = stride == 2 ? 4 : 16, K = stride == 2 ? 4 * Cin : Cin;
-  const long n = (long)((K + 31) / 32) * taps * Cout * 32 + (long)((Cout + 31) / 32) * taps * K * 32;
-  return (n + 2047) / 2048;
+  return pack4x4_layer_blocks(Cout, Cin, stride == 2 ? 1 : 0);
 }
 
 // desc: device long[nlayers][7] = {w (fp32 master), wf, wd, Cout, Cin, stride == 2, first block}; total = all blocks
 extern "C" int s2s_pack_conv4x4_batched(int dtype, const void* desc, int nlayers, long total, void* stream) {
   if (!desc) return S2S_ERR_NULL;
   if (nlayers <= 0 || total <= 0 || total >= (1L << 31)) return S2S_ERR_SHAPE;
-  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
-  hipLaunchKernelGGL(pack4x4_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
-                     nlayers, dtype);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(pack4x4_batched_kernel<bf16_t>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)desc, nlayers);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pack4x4_batched_kernel<float>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)desc, nlayers);
+  else return S2S_ERR_DTYPE;
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -786,8 +786,11 @@ def convkxk(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
         p2, ld2 = _nhwc(out2)
     if bias is not None and bias.numel() != (bias_mod or cout):
         raise RuntimeError("stain2stain_amd: convkxk bias length does not match (cout, bias_mod)")
+    nsplit = _L().s2s_convkxk_ksplit(_dt(x), B, H, W, cout, cin, ks)
+    _native.check(min(nsplit, 0), "convkxk_ksplit")
+    kwork = torch.empty((nsplit, B * H * W, cout), dtype=torch.float32, device=x.device) if nsplit > 1 else None
     rc = _L().s2s_convkxk_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), int(bias_mod), py, ldy, p2, ld2, int(act),
-                               float(slope), 0, B, H, W, cout, ks, pad, _stream())
+                               float(slope), 0, _f32(kwork), B, H, W, cout, ks, pad, _stream())
     _native.check(rc, "convkxk")
     return y
 

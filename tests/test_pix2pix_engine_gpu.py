@@ -32,10 +32,11 @@ def _l2(a, b):
 # kernels
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 24), (3, 8, 8, 64, 136), (1, 40, 32, 8, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 24), (3, 8, 8, 64, 136), (1, 40, 32, 8, 64), (2, 8, 8, 256, 64)])
 def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
     """The three layer kinds in both dtypes: forward, data gradient and weight gradient against torch's conv on the CPU
-    (operands rounded to the storage dtype first, so the comparison sees the kernel and not the rounding of its inputs)."""
+    (operands rounded to the storage dtype first, so the comparison sees the kernel and not the rounding of its inputs).
+    The 8x8 shapes take the split-K path in bf16 (few output tiles, long reduction)."""
     from stain2stain_amd import ops
     B, H, W, cin, cout = shape
     g = torch.Generator().manual_seed(B * 1000 + H)
@@ -85,6 +86,28 @@ def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
     gw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
     ops.convkxk_wgrad(nhwc(gy), nhwc(x), gw, 4)
     assert relerr(gw, wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_weight_packing_equals_the_per_layer_kernel(dtype):
+    """s2s_pack_conv4x4_batched (LDS-tiled for channel counts that are multiples of 32, element-wise for the 8-channel
+    image-side layers) against s2s_pack_conv4x4_t, bit for bit, both strides."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(3)
+    layers = [(64, 32, 2), (32, 96, 1), (8, 64, 2), (64, 8, 1), (128, 64, 2), (8, 32, 1)]
+    ws = [torch.randn(o, c, 4, 4, generator=g).to(DEV) for o, c, _ in layers]
+    rows, start, outs = [], 0, []
+    for w, (o, c, st) in zip(ws, layers):
+        taps, K = (4, 4 * c) if st == 2 else (16, c)
+        wf = torch.zeros(((K + 31) // 32, taps, o, 32), dtype=dtype, device=DEV)
+        wd = torch.zeros(((o + 31) // 32, taps, K, 32), dtype=dtype, device=DEV)
+        outs.append((wf, wd))
+        rows.append([w.data_ptr(), wf.data_ptr(), wd.data_ptr(), o, c, 1 if st == 2 else 0, start])
+        start += ops._L().s2s_pack_conv4x4_blocks(o, c, st)
+    ops.pack_conv4x4_batched(torch.tensor(rows, dtype=torch.int64, device=DEV), start, dtype)
+    for w, (o, c, st), (wf, wd) in zip(ws, layers, outs):
+        rf, rd = ops.pack_conv4x4_t(w, st, dtype)
+        assert torch.equal(wf, rf) and torch.equal(wd, rd), (o, c, st)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
