@@ -286,7 +286,20 @@ int s2s_convkxk_ksplit(int dtype, int B, int H, int W, int Cout, int cin, int ks
  * nn.ConvTranspose2d's [Cin][Cout][4][4]).  part: float[s2s_convkxk_wgrad_splits()][ks*ks][Cout][cin] scratch. */
 int s2s_convkxk_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout, int ks);
 int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin, float* part,
-                           float* grad, int layout, int accumulate, int B, int H, int W, int ks, void* stream);
+                           float* grad, int layout, int accumulate, int B, int H, int W, int ks, int x_plain, void* stream);
+/* The 4x4 stride-2 layers without a layout pass (bf16): s2s_conv4x4s2_nhwc reads the PLAIN input x [B][2H][2W][Cin]
+ * (Cin a power of two; the loader does the space-to-depth in its addresses) -> y [B][H][W][Cout];
+ * s2s_convt4x4s2_nhwc is the transposed layer / the convolution's data gradient by sub-pixel phase, x [B][h][w][Cin] ->
+ * PLAIN y [B][2h][2w][C] (C % 64 == 0), wd = the data-gradient operand of s2s_pack_conv4x4.  kwork (optional):
+ * float[..._ksplit()][output pixels][channels] for the split-K form of the small maps.  The weight gradient takes the
+ * plain tensor with x_plain = 1 in s2s_convkxk_wgrad_nhwc (cin = 4 C stays the virtual channel count). */
+int s2s_conv4x4s2_ksplit(int B, int H, int W, int Cout, int Cin);
+int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wf, const float* bias, void* y, int ldy,
+                       void* y2, int ldy2, int act, float act_slope, float* kwork, int B, int H, int W, int Cout,
+                       void* stream);
+int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin);
+int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wd, const float* bias, void* y, int ldy,
+                        float* kwork, int B, int h, int w, int C, void* stream);
 /* InstanceNorm + LeakyReLU with a second output y2 = relu(z) (pixel stride ldy2, optional) and, backward, a second
  * incoming gradient g2 (wrt y2, optional): dz = z > 0 ? g + g2 : slope * g.  Otherwise as s2s_instnorm_lrelu_fwd/bwd. */
 int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,

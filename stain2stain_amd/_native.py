@@ -84,7 +84,7 @@ def declared_prototypes() -> Dict[str, tuple]:
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos: Dict[str, tuple] = {}
-    for ret, name, args in re.findall(r"\b(int|long)\s+(s2s_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+    for ret, name, args in re.findall(r"\b(int|long)\s+(s2s_\w+)\s*\(([^)]*)\)\s*;", text):
         argtypes = []
         for a in [x.strip() for x in args.split(",") if x.strip()]:
             if "*" in a:

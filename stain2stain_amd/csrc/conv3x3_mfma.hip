@@ -57,6 +57,7 @@ struct Conv3x3Args {
   // adds them up and applies bias / activation.  nullptr = one workgroup per tile, epilogue in the kernel.
   float* kpart;
   int ksplit;
+  int lgc;        // convkxk MODE 1: log2 of the real input channel count (a.c0 = 4 << lgc virtual channels)
   int bias_mod;   // bias index = channel % bias_mod (= Cout normally; Cout / 4 for the transposed 4x4 layers, whose four
                   // sub-pixel channel groups share one bias vector)
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
@@ -647,12 +648,16 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// Where a tile's output pixel (gy, gx) goes: plain (os = 1) or, for the sub-pixel phases of a transposed convolution,
+// pixel (os gy + oy, os gx + ox) of the OH x OW output.
+struct OutMap { int os, oy, ox, OH, OW; };
+
 // `tid` is the thread's index inside its group of 256 (a whole workgroup, or one half of a ping-pong workgroup),
 // `smem` that group's staging area, `stat_row` the tile's row in stat_part; the barriers are workgroup-wide.
 template <int TH, int TW, int BN, int WM, int WN, int LDS_MAIN, bool AFFINE>
 __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
                                                 const float (&bias)[(BN / WN) / 16][4], char* smem, int img, int y0,
-                                                int x0p, int n0, int tid, long stat_row) {
+                                                int x0p, int n0, int tid, long stat_row, const OutMap om) {
   using T = bf16_t;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   T* __restrict__ yout = static_cast<T*>(a.y);
@@ -721,7 +726,7 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
       const int gy = y0 + py, gx = x0p + px, n = n0 + c * 8;
       if (full || (gy < a.H && gx < a.W && n < a.Cout)) {
         const bf16x8 val = *reinterpret_cast<const bf16x8*>(otile + ml * RS + c * 16);
-        const long opix = ((long)img * a.H + gy) * a.W + gx;
+        const long opix = ((long)img * om.OH + gy * om.os + om.oy) * om.OW + gx * om.os + om.ox;
         if (!(a.dbg & 8)) *reinterpret_cast<bf16x8*>(yout + opix * a.ldy + n) = val;
         if (a.y2) {
           bf16x8 r8;
@@ -922,8 +927,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     });
   }
   if (a.dbg & 16) return;
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
-  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+  const OutMap om{1, 0, 0, a.H, a.W};
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
   if ((a.dbg & 64) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4 + 0] = c0_; g_clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter(); g_clk[blockIdx.x * 4 + 2] = w0_; g_clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
 
@@ -956,8 +962,17 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
 // Same halo image, weight ring, swizzle, operand order and epilogue as conv3x3_dma16_kernel; weights packed
 // [chunk][tap a*KS+b][Cout][32].  One source tensor.
 // =========================================================================================================
-template <int TH, int TW, int BN, int WM, int WN, int NS, int KS, int PAD>
+// MODE 1 (KS = 2, PAD = 0): the 4x4 stride-2 convolution straight from the PLAIN input [B][2H][2W][C] -- the halo loader
+//   does the space-to-depth in its DMA addresses: virtual channel (r*2+s)*C + c of cell (p, q) is channel c of pixel
+//   (2p + r - 1, 2q + s - 1), zero outside; a.c0 = 4 C (C a power of two, a.lgc its log2).  No layout pass, no border cells.
+// MODE 2 (KS = 2): the 4x4 stride-2 TRANSPOSED convolution (and the stride-2 convolution's data gradient) by sub-pixel
+//   phase: phase (r, s) = blockIdx.z / ksplit is a 2x2 convolution with padding (r, s) over the h x w input whose
+//   output pixel (i, j) is pixel (2i + 1 - r, 2j + 1 - s) of the plain 2h x 2w output; its weights are rows
+//   [phase C, phase C + C) of the packed data-gradient operand (4 C rows).  a.H / a.W = h, w; a.Cout = C.  The four
+//   phases tile h x w exactly (the space-to-depth form computes (h+1) x (w+1) cells) and nothing is re-laid out.
+template <int TH, int TW, int BN, int WM, int WN, int NS, int KS, int PAD, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
+  static_assert(MODE == 0 || KS == 2, "the fused layouts exist for the 2x2-tap forms");
   using T = bf16_t;
   constexpr int TAPS = KS * KS;
   static_assert(KS >= 2 && KS <= 5, "the halo row has four spare columns");
@@ -986,9 +1001,12 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   const int img = bt / a.tilesY;
   const int y0 = ty * TH, x0p = tx * TW;
   const int n0 = blockIdx.y * BN;
-  const int Hi = a.H + KS - 1 - 2 * PAD, Wi = a.W + KS - 1 - 2 * PAD;
-  // this workgroup's chunk range [c_lo, c_hi): all of them, or the blockIdx.z-th share of a split-K launch
-  const int c_lo = (int)(((long)blockIdx.z * a.nchunk) / gridDim.z), c_hi = (int)(((long)(blockIdx.z + 1) * a.nchunk) / gridDim.z);
+  const int phase = MODE == 2 ? (int)blockIdx.z / a.ksplit : 0, zk = (int)blockIdx.z - phase * a.ksplit;
+  const int pad_y = MODE == 2 ? (phase >> 1) : PAD, pad_x = MODE == 2 ? (phase & 1) : PAD;
+  const int Hi = MODE == 2 ? a.H : a.H + KS - 1 - 2 * PAD, Wi = MODE == 2 ? a.W : a.W + KS - 1 - 2 * PAD;
+  // this workgroup's chunk range [c_lo, c_hi): all of them, or the zk-th share of a split-K launch
+  const int c_lo = (int)(((long)zk * a.nchunk) / a.ksplit), c_hi = (int)(((long)(zk + 1) * a.nchunk) / a.ksplit);
+  const int wrows = MODE == 2 ? 4 * a.Cout : a.Cout, wrow0 = (MODE == 2 ? phase * a.Cout : 0) + n0;
 
   const int drow = lane >> 2, dslot = lane & 3;
   int apix[HG], apc[HG];
@@ -996,8 +1014,10 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   for (int j = 0; j < HG; ++j) {
     const int row = (wave + 4 * j) * 16 + drow;
     const int hy = row / HP, hx = row - hy * HP;
-    const int gy = y0 - PAD + hy, gx = x0p - PAD + hx;
-    apix[j] = (row < ROWS && hx < TW + KS - 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? (img * Hi + gy) * Wi + gx : -1;
+    const int gy = y0 - pad_y + hy, gx = x0p - pad_x + hx;
+    const bool inside = row < ROWS && hx < TW + KS - 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+    if (MODE == 1) apix[j] = inside ? ((gy << 16) | gx) : -1;        // cell coordinates; the pixel depends on the chunk
+    else apix[j] = inside ? (img * Hi + gy) * Wi + gx : -1;
     apc[j] = (dslot ^ ((-(hx >> 2)) & 3)) * 8;
   }
   const char* wptr[BG];
@@ -1006,8 +1026,8 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   for (int j = 0; j < BG; ++j) {
     const int n = (wave + 4 * j) * 16 + drow;
     const bool ok = n0 + n < a.Cout;
-    wptr[j] = ok ? wp + (long)c_lo * TAPS * a.Cout * 64 + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
-    wstep[j] = ok ? a.Cout * 64 : 0;
+    wptr[j] = ok ? wp + (long)c_lo * TAPS * wrows * 64 + ((long)(wrow0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
+    wstep[j] = ok ? wrows * 64 : 0;
   }
   auto dma_halo = [&](int c) {
     char* dst = ldsA + (c & 1) * A_BYTES + wave * 1024;
@@ -1015,7 +1035,16 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
     for (int j = 0; j < HG; ++j) {
       const int ch = c * 32 + apc[j];
       const void* g = g_zero_page;
-      if (apix[j] >= 0 && ch < a.c0) g = x0 + (long)apix[j] * a.ld0 + ch;
+      if (MODE == 1) {
+        if (apix[j] >= 0 && ch < a.c0) {
+          const int rs = ch >> a.lgc, cc = ch & ((1 << a.lgc) - 1);
+          const int py = 2 * (apix[j] >> 16) + (rs >> 1) - 1, px = 2 * (apix[j] & 0xffff) + (rs & 1) - 1;
+          if ((unsigned)py < (unsigned)(2 * a.H) && (unsigned)px < (unsigned)(2 * a.W))
+            g = x0 + ((long)(img * 2 * a.H + py) * (2 * a.W) + px) * a.ld0 + cc;
+        }
+      } else if (apix[j] >= 0 && ch < a.c0) {
+        g = x0 + (long)apix[j] * a.ld0 + ch;
+      }
       dma16(g, dst + j * 4096);
     }
   };
@@ -1100,17 +1129,18 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_s_barrier();
     });
   }
+  const OutMap om = MODE == 2 ? OutMap{2, 1 - pad_y, 1 - pad_x, 2 * a.H, 2 * a.W} : OutMap{1, 0, 0, a.H, a.W};
   if (a.kpart) {
     // split-K: the fp32 partial tile straight from the accumulators (a lane's four registers = four consecutive
     // channels of one pixel: one 16-byte store)
-    float* const kpz = a.kpart + (long)blockIdx.z * ((long)a.B * a.H * a.W) * a.Cout;
+    float* const kpz = a.kpart + (long)zk * ((long)a.B * om.OH * om.OW) * a.Cout;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = wm * WTM + mi * 16 + cl;
       const int py = m / TW, px = m - py * TW;
       const int gy = y0 + py, gx = x0p + px;
       if (gy < a.H && gx < a.W) {
-        float* const row = kpz + (((long)img * a.H + gy) * a.W + gx) * a.Cout;
+        float* const row = kpz + (((long)img * om.OH + gy * om.os + om.oy) * om.OW + gx * om.os + om.ox) * a.Cout;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int n = n0 + wn * WTN + ni * 16 + 4 * kp;
@@ -1120,11 +1150,13 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
     }
     return;
   }
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
-  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x);
+  // (per-tile statistics rows are only defined for the single-phase forms)
+  const long stat_row = MODE == 2 ? -1 : (long)blockIdx.x;
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int KS, int PAD>
+template <int TH, int TW, int BN, int WM, int WN, int KS, int PAD, int MODE = 0>
 int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   constexpr int NS = 4;
   constexpr int ROWS = (TH + KS - 1) * (TW + 4);
@@ -1133,10 +1165,11 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
-  auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD>;
+  auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD, MODE>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
-  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.kpart ? a.ksplit : 1);
+  if (!a.kpart) a.ksplit = 1;
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit * (MODE == 2 ? 4 : 1));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -1476,7 +1509,7 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
@@ -1602,4 +1635,91 @@ extern "C" int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, co
   if (pad != 1 && pad != 2) return S2S_ERR_SHAPE;
   return s2s_convkxk_nhwc(dtype, x, ldx, cin, w_packed, bias, 0, y, ldy, nullptr, 8, 0, 0.f, stat_part, nullptr, B, H, W, Cout,
                           4, pad, stream);
+}
+
+// ---- the 4x4 stride-2 layers without a layout pass (bf16) -----------------------------------------------------------
+// s2s_conv4x4s2_nhwc: nn.Conv2d(k=4, s=2, p=1) from the PLAIN input x [B][2H][2W][Cin] (Cin a power of two >= 8) to
+//   y [B][H][W][Cout]; wf = the forward operand of s2s_pack_conv4x4 (stride 2).  act / y2 / kwork as s2s_convkxk_nhwc.
+// s2s_convt4x4s2_nhwc: nn.ConvTranspose2d(k=4, s=2, p=1) from x [B][h][w][Cin] to the PLAIN output y [B][2h][2w][C]
+//   (C % 64 == 0: narrower layers keep the space-to-depth form), by sub-pixel phase; wd = the data-gradient operand of
+//   s2s_pack_conv4x4 for the weight read as [O = Cin][C][4][4].  The same call is the data gradient of
+//   s2s_conv4x4s2_nhwc (x = dY, wd of the convolution's own weight, C = its input channels).
+static int s2_ksplit(long base, int nchunk) {
+  if (base >= 192 || nchunk < 8) return 1;
+  long sp = (512 + base - 1) / base;
+  if (sp > nchunk / 4) sp = nchunk / 4;
+  if (sp > 32) sp = 32;
+  return sp < 2 ? 1 : (int)sp;
+}
+
+extern "C" int s2s_conv4x4s2_ksplit(int B, int H, int W, int Cout, int Cin) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
+  return s2_ksplit((long)B * cdiv(H, 8) * cdiv(W, W > 16 ? 32 : 16) * cdiv(Cout, Cout > 64 ? 128 : 64), cdiv(4 * Cin, 32));
+}
+
+extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wf, const float* bias, void* y,
+                                  int ldy, void* y2, int ldy2, int act, float act_slope, float* kwork, int B, int H, int W,
+                                  int Cout, void* stream) {
+  if (!x || !wf || !y) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin < 8 || (Cin & (Cin - 1)) || (ldx % 8) || ldx < Cin || (Cout % 8) || (ldy % 8) || ldy < Cout) return S2S_ERR_SHAPE;
+  if (y2 && ((ldy2 % 8) || ldy2 < Cout)) return S2S_ERR_SHAPE;
+  if (H >= 32768 || W >= 32768 || (long)B * 4 * H * W >= (1L << 31)) return S2S_ERR_SHAPE;     // 16-bit cell coordinates in the loader
+  if (((uintptr_t)x & 15) || ((uintptr_t)wf & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return S2S_ERR_ALIGN;
+  Conv3x3Args a;
+  a.x0 = x; a.x1 = nullptr; a.w = wf; a.bias = bias; a.y = y; a.stat_part = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
+  a.bias_mod = Cout; a.lgc = __builtin_ctz((unsigned)Cin);
+  a.ld0 = ldx; a.c0 = 4 * Cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(4 * Cin, 32); a.relu = 0; a.dbg = 0;
+  a.tilesX = a.tilesY = 0;
+  a.ksplit = kwork ? s2s_conv4x4s2_ksplit(B, H, W, Cout, Cin) : 1;
+  a.kpart = a.ksplit > 1 ? kwork : nullptr;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wide = W > 16, big = Cout > 64;
+  int rc;
+  if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0, 1>(a, s);
+  else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0, 1>(a, s);
+  if (rc != S2S_OK || !a.kpart) return rc;
+  const long npix = (long)B * H * W, pieces = npix * (Cout / 8);
+  long nb = (pieces + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(convk_splitk_reduce_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, npix);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin) {
+  if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
+  return s2_ksplit(4L * B * cdiv(h, 8) * cdiv(w, w > 16 ? 32 : 16) * cdiv(C, C > 64 ? 128 : 64), cdiv(Cin, 32));
+}
+
+extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wd, const float* bias, void* y,
+                                   int ldy, float* kwork, int B, int h, int w, int C, void* stream) {
+  if (!x || !wd || !y) return S2S_ERR_NULL;
+  if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
+  if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C % 64) || Cin <= 0 || (Cin % 8) || (ldx % 8) || ldx < Cin || (ldy % 8) || ldy < C) return S2S_ERR_SHAPE;
+  if ((long)B * 4 * h * w >= (1L << 31)) return S2S_ERR_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)wd & 15) || ((uintptr_t)y & 15)) return S2S_ERR_ALIGN;
+  Conv3x3Args a;
+  a.x0 = x; a.x1 = nullptr; a.w = wd; a.bias = bias; a.y = y; a.stat_part = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8;
+  a.bias_mod = C; a.lgc = 0;
+  a.ld0 = ldx; a.c0 = Cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
+  a.B = B; a.H = h; a.W = w; a.Cout = C; a.nchunk = cdiv(Cin, 32); a.relu = 0; a.dbg = 0;
+  a.tilesX = a.tilesY = 0;
+  a.ksplit = kwork ? s2s_convt4x4s2_ksplit(B, h, w, C, Cin) : 1;
+  a.kpart = a.ksplit > 1 ? kwork : nullptr;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wide = w > 16, big = C > 64;
+  int rc;
+  if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1, 2>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1, 2>(a, s);
+  else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1, 2>(a, s);
+  if (rc != S2S_OK || !a.kpart) return rc;
+  const long npix = (long)B * 4 * h * w, pieces = npix * (C / 8);
+  long nb = (pieces + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(convk_splitk_reduce_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, npix);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }

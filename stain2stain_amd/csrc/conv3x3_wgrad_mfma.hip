@@ -29,6 +29,7 @@ struct WgradArgs {
   float* part;
   int lddy, Cout, ld0, c0, ld1, c1;
   int B, H, W, tilesY, tilesX, ntiles, S;
+  int lgc;   // conv2x2_wgrad_dma_kernel<.., S2D = true>: log2 of the real channel count of the plain X tensor
 };
 
 namespace {
@@ -477,7 +478,11 @@ inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
 // barrier per pixel tile), same transposed fragment reads, four accumulators instead of nine; the halo is
 // (TH+1) x (TW+1) and is never out of range for a tile inside the output.
 // =========================================================================================================
-template <int TH, int TW>
+// S2D: X is given as the PLAIN tensor [B][2H][2W][C] (a.c0 = 4 C virtual channels, C = 1 << a.lgc) and the loader does the
+// space-to-depth in its DMA addresses, as convkxk_dma16_kernel's MODE 1 does: channel (r*2+s)*C + c of cell (p, q) is
+// channel c of pixel (2p + r - 1, 2q + s - 1), zero outside.  A lane's channel piece is fixed for the whole kernel, so
+// (r, s, c) are per-lane constants.
+template <int TH, int TW, bool S2D = false>
 __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) {
   using T = bf16_t;
   constexpr int NT = 4;
@@ -532,8 +537,16 @@ __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) 
     const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
     const int ci = ci0 + half * 32 + dslot * 8;
     x_hy[j] = px / HW_; x_hx[j] = px - x_hy[j] * HW_;
-    x_ptr[j] = (px < HALO && ci < cin) ? x0 + ci : nullptr;
-    x_off[j] = (x_hy[j] * Wi + x_hx[j]) * a.ld0;
+    if (S2D) {
+      const int rs = ci >> a.lgc;
+      x_ptr[j] = (px < HALO && ci < cin) ? x0 + (ci & ((1 << a.lgc) - 1)) : nullptr;
+      x_hy[j] = 2 * x_hy[j] + (rs >> 1) - 1;            // plain-pixel offsets relative to (2 y0, 2 xs)
+      x_hx[j] = 2 * x_hx[j] + (rs & 1) - 1;
+      x_off[j] = 0;
+    } else {
+      x_ptr[j] = (px < HALO && ci < cin) ? x0 + ci : nullptr;
+      x_off[j] = (x_hy[j] * Wi + x_hx[j]) * a.ld0;
+    }
   }
 
   auto dma_tile = [&](int tile, int buf) {
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) 
     const int y0 = ty * TH, xs = tx * TW;
     const long pixbase = (long)(img * a.H + y0) * a.W + xs;           // dY (output) pixel, wave-uniform
     const long xbase = (long)(img * Hi + y0) * Wi + xs;               // X (input) pixel of the halo origin
-    const bool interior = y0 + TH <= a.H && xs + TW <= a.W;           // then the halo is inside the input too
+    const bool interior = !S2D && y0 + TH <= a.H && xs + TW <= a.W;   // then the halo is inside the input too
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
     if (interior) {
 #pragma unroll
@@ -567,9 +580,15 @@ __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) 
       }
 #pragma unroll
       for (int j = 0; j < XG; ++j) {
-        const int gy = y0 + x_hy[j], gx = xs + x_hx[j];
         const void* src = g_wgrad_zero_page;
-        if (x_ptr[j] && gy < Hi && gx < Wi) src = x_ptr[j] + xbase * a.ld0 + x_off[j];
+        if (S2D) {
+          const int py = 2 * y0 + x_hy[j], px = 2 * xs + x_hx[j];
+          if (x_ptr[j] && (unsigned)py < (unsigned)(2 * a.H) && (unsigned)px < (unsigned)(2 * a.W))
+            src = x_ptr[j] + ((long)(img * 2 * a.H + py) * (2 * a.W) + px) * a.ld0;
+        } else {
+          const int gy = y0 + x_hy[j], gx = xs + x_hx[j];
+          if (x_ptr[j] && gy < Hi && gx < Wi) src = x_ptr[j] + xbase * a.ld0 + x_off[j];
+        }
         dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
       }
     }
@@ -980,7 +999,7 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   WgradArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
-  a.B = B; a.H = H; a.W = W;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0;
   a.S = s2s_conv3x3_wgrad_splits(dtype, B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
@@ -1021,7 +1040,7 @@ extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0;
   a.S = conv2x2_wgrad_splits(B, H, W, cin, Cout);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1067,7 +1086,7 @@ extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0;
   a.S = s2s_conv4x4s1_wgrad_splits(B, H, W, cin, Cout);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1124,18 +1143,21 @@ static int launch_wgrad_rs(WgradArgs& a, hipStream_t s) {
 
 extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x, int ldx, int cin,
                                       float* part, float* grad, int layout, int accumulate, int B, int H, int W, int ks,
-                                      void* stream) {
+                                      int x_plain, void* stream) {
   if (!dy || !x || !part || !grad) return S2S_ERR_NULL;
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0 || (ks != 2 && ks != 4)) return S2S_ERR_SHAPE;
   if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8) || (layout != 0 && layout != 1)) return S2S_ERR_SHAPE;
   if (ks == 2 && layout == 1 && (cin % 32)) return S2S_ERR_SHAPE;          // cin = 4 C with C a multiple of 8
+  // x_plain: X is the plain [B][2H][2W][C] tensor (bf16, ks = 2, C a power of two), space-to-depth done by the loader
+  if (x_plain && (dtype != S2S_BF16 || ks != 2 || (cin % 32) || ((cin / 4) & (cin / 4 - 1)) || ldx < cin / 4)) return S2S_ERR_SHAPE;
+  if (x_plain && (H >= 16384 || W >= 16384)) return S2S_ERR_SHAPE;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
   if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0;
   a.S = s2s_convkxk_wgrad_splits(dtype, B, H, W, cin, Cout, ks);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1147,10 +1169,18 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   } else if (ks == 2) {
     constexpr int XROWS = ((TH + 1) * (TW + 1) + 31) / 32 * 32;
     constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
-    auto kern = conv2x2_wgrad_dma_kernel<TH, TW>;
-    static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
-    if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc2;
-    hipLaunchKernelGGL(kern, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S), dim3(256), lds, s, a);
+    if (x_plain) {
+      a.lgc = __builtin_ctz((unsigned)(cin / 4));
+      auto kern = conv2x2_wgrad_dma_kernel<TH, TW, true>;
+      static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+      if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc2;
+      hipLaunchKernelGGL(kern, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S), dim3(256), lds, s, a);
+    } else {
+      auto kern = conv2x2_wgrad_dma_kernel<TH, TW, false>;
+      static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+      if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc2;
+      hipLaunchKernelGGL(kern, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S), dim3(256), lds, s, a);
+    }
   } else {
     constexpr int KS = 4;
     constexpr int XROWS = (TH * (TW + KS - 1) + 31) / 32 * 32;

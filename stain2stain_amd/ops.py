@@ -795,19 +795,21 @@ def convkxk(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     return y
 
 
-def _kxk_wgrad_flops(dy, x, grad, ks, **kw) -> float:
+def _kxk_wgrad_flops(dy, x, grad, ks, accumulate=False, x_plain=False, **kw) -> float:
     B, H, W, cout = dy.shape
-    return 2.0 * B * H * W * cout * ks * ks * x.shape[3]
+    return 2.0 * B * H * W * cout * 16 * (x.shape[3] if (x_plain or ks == 4) else x.shape[3] // 4)
 
 
 @_timed("convkxk_wgrad_mfma", _kxk_wgrad_flops)
-def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int, accumulate: bool = False) -> None:
+def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int, accumulate: bool = False,
+                  x_plain: bool = False) -> None:
     """grad (fp32, nn.Conv2d layout [Cout][C][4][4]) (+)= weight gradient: dy [B,H,W,Cout]; x [B,H+1,W+1,cin] with
-    cin = 4 C (ks = 2, space-to-depth image) or C (ks = 4)."""
+    cin = 4 C (ks = 2, space-to-depth image) or C (ks = 4); ``x_plain`` (ks = 2, bf16): x is the plain [B,2H,2W,C] tensor
+    and the kernel's loader does the space-to-depth."""
     B, H, W, cout = dy.shape
-    cin = x.shape[3]
+    cin = 4 * x.shape[3] if x_plain else x.shape[3]
     C = cin // 4 if ks == 2 else cin
-    if x.dtype != dy.dtype or tuple(x.shape[:3]) != (B, H + 1, W + 1):
+    if x.dtype != dy.dtype or tuple(x.shape[:3]) != ((B, 2 * H, 2 * W) if x_plain else (B, H + 1, W + 1)):
         raise RuntimeError("stain2stain_amd: convkxk_wgrad operand mismatch")
     if grad.numel() != cout * C * 16 or grad.dtype != torch.float32 or not grad.is_contiguous():
         raise RuntimeError("stain2stain_amd: convkxk_wgrad gradient buffer has the wrong size")
@@ -817,7 +819,7 @@ def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int
     _native.check(min(s, 0), "convkxk_wgrad_splits")
     part = torch.empty((s, ks * ks, cout, cin), dtype=torch.float32, device=dy.device)
     rc = _L().s2s_convkxk_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), grad.data_ptr(), 1,
-                                     int(accumulate), B, H, W, ks, _stream())
+                                     int(accumulate), B, H, W, ks, int(x_plain), _stream())
     _native.check(rc, "convkxk_wgrad")
 
 
@@ -982,3 +984,58 @@ def channel_sum_into(x: torch.Tensor, out: torch.Tensor) -> None:
     work = torch.empty(2 * C * nb, dtype=torch.float32, device=x.device)
     rc = _L().s2s_channel_sum(_dt(x), px, ldx, _f32(work), out.data_ptr(), npix, C, 0, _stream())
     _native.check(rc, "channel_sum")
+
+
+def fused_s2_ok(dtype: torch.dtype, c: int) -> bool:
+    """The layout-free 4x4 stride-2 kernels (space-to-depth in the loader) take bf16 and a power-of-two channel count."""
+    return dtype == torch.bfloat16 and c >= 8 and (c & (c - 1)) == 0
+
+
+@_timed("convkxk_mfma", lambda x, w_packed, bias, cout, **kw: 2.0 * x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) * cout
+        * 16 * x.shape[3])
+def conv4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, *, act: bool = False,
+              slope: float = 0.0, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Conv2d(k=4, s=2, p=1) from the plain NHWC bf16 input [B,2H,2W,Cin] (no space-to-depth pass)."""
+    B, Hi, Wi, cin = x.shape
+    H, W = Hi // 2, Wi // 2
+    if Hi % 2 or Wi % 2 or not fused_s2_ok(x.dtype, cin) or w_packed.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: conv4x4s2 wants bf16, even sizes and a power-of-two channel count")
+    if w_packed.numel() != ((4 * cin + 31) // 32) * 4 * cout * 32:
+        raise RuntimeError("stain2stain_amd: conv4x4s2 packed weight has the wrong size")
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device)
+    p2, ld2 = (0, 8) if out2 is None else _nhwc(out2)
+    if out2 is not None and tuple(out2.shape) != (B, H, W, cout):
+        raise RuntimeError("stain2stain_amd: conv4x4s2 second output mismatch")
+    nsplit = _L().s2s_conv4x4s2_ksplit(B, H, W, cout, cin)
+    _native.check(min(nsplit, 0), "conv4x4s2_ksplit")
+    kwork = torch.empty((nsplit, B * H * W, cout), dtype=torch.float32, device=x.device) if nsplit > 1 else None
+    rc = _L().s2s_conv4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), y.data_ptr(), cout, p2, ld2, int(act),
+                                 float(slope), _f32(kwork), B, H, W, cout, _stream())
+    _native.check(rc, "conv4x4s2")
+    return y
+
+
+@_timed("convkxk_mfma", lambda x, w_packed, bias, cout, **kw: 2.0 * x.shape[0] * 4 * x.shape[1] * x.shape[2] * cout * 4
+        * x.shape[3])
+def convT4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, *,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.ConvTranspose2d(k=4, s=2, p=1) (= the stride-2 convolution's data gradient) by sub-pixel phase: NHWC bf16
+    [B,h,w,Cin] -> plain [B,2h,2w,cout], cout % 64 == 0; w_packed = the data-gradient operand."""
+    B, h, w, cin = x.shape
+    if x.dtype != torch.bfloat16 or w_packed.dtype != x.dtype or cout % 64:
+        raise RuntimeError("stain2stain_amd: convT4x4s2 wants bf16 and cout % 64 == 0")
+    if w_packed.numel() != ((cin + 31) // 32) * 4 * 4 * cout * 32:
+        raise RuntimeError("stain2stain_amd: convT4x4s2 packed weight has the wrong size")
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device) if out is None else out
+    if tuple(y.shape) != (B, 2 * h, 2 * w, cout) or y.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: convT4x4s2 output buffer mismatch")
+    py, ldy = _nhwc(y)
+    nsplit = _L().s2s_convt4x4s2_ksplit(B, h, w, cout, cin)
+    _native.check(min(nsplit, 0), "convT4x4s2_ksplit")
+    kwork = torch.empty((nsplit, B * 4 * h * w, cout), dtype=torch.float32, device=x.device) if nsplit > 1 else None
+    rc = _L().s2s_convt4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), py, ldy, _f32(kwork), B, h, w, cout,
+                                  _stream())
+    _native.check(rc, "convT4x4s2")
+    return y

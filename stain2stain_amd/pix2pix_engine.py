@@ -122,30 +122,44 @@ class _Packer:
 # ----------------------------------------------------------------------------------------------------------------------
 # layer forward / backward on the kernels
 # ----------------------------------------------------------------------------------------------------------------------
-def _conv_s2_fwd(l: _Layer, xs: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None) -> torch.Tensor:
-    """nn.Conv2d(k=4, s=2, p=1) from the space-to-depth image xs of its input."""
-    return ops.convkxk(xs, l.wf, None if l.bias is None else l.bias.detach(), l.conv_out, 2, 0, act=act, slope=slope,
-                       out2=out2)
+def _conv_s2_fwd(l: _Layer, x: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None):
+    """nn.Conv2d(k=4, s=2, p=1) of the plain NHWC tensor x.  Returns (y, saved): ``saved`` is what the weight gradient
+    reads -- x itself on the layout-free bf16 kernels (the loader does the space-to-depth in its addresses), else the
+    explicit space-to-depth image (fp32 parity mode)."""
+    bias = None if l.bias is None else l.bias.detach()
+    if ops.fused_s2_ok(x.dtype, x.shape[3]):
+        return ops.conv4x4s2(x, l.wf, bias, l.conv_out, act=act, slope=slope, out2=out2), x
+    xs = ops.space_to_depth_pad1_t(x)
+    return ops.convkxk(xs, l.wf, bias, l.conv_out, 2, 0, act=act, slope=slope, out2=out2), xs
 
 
-def _conv_s2_bwd(l: _Layer, g: torch.Tensor, xs: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True):
+def _conv_s2_bwd(l: _Layer, g: torch.Tensor, saved: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True):
     if want_w:
-        ops.convkxk_wgrad(g, xs, gw, 2)
+        ops.convkxk_wgrad(g, saved, gw, 2, x_plain=(saved.shape[3] == l.conv_in))     # plain input vs space-to-depth image
     if not need_dx:
         return None
+    if g.dtype == torch.bfloat16 and l.conv_in % 64 == 0:
+        return ops.convT4x4s2(g, l.wd, None, l.conv_in)                  # data gradient by sub-pixel phase, plain output
     return ops.depth_to_space_unpad1_t(ops.convkxk(g, l.wd, None, 4 * l.conv_in, 2, 1))
 
 
 def _conv_t2_fwd(l: _Layer, x: torch.Tensor) -> torch.Tensor:
     """nn.ConvTranspose2d(k=4, s=2, p=1): [B,h,w,Cin] -> [B,2h,2w,Cout]."""
-    # the four sub-pixel channel groups of the space-to-depth output share the layer's bias (bias_mod)
-    return ops.depth_to_space_unpad1_t(ops.convkxk(x, l.wd, None if l.bias is None else l.bias.detach(), 4 * l.conv_out, 2,
-                                                   1, bias_mod=l.conv_out))
+    bias = None if l.bias is None else l.bias.detach()
+    if x.dtype == torch.bfloat16 and l.conv_out % 64 == 0:
+        return ops.convT4x4s2(x, l.wd, bias, l.conv_out)
+    # space-to-depth form: the four sub-pixel channel groups of the output share the layer's bias (bias_mod)
+    return ops.depth_to_space_unpad1_t(ops.convkxk(x, l.wd, bias, 4 * l.conv_out, 2, 1, bias_mod=l.conv_out))
 
 
 def _conv_t2_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, need_dx: bool = True):
+    # weight gradient with the roles exchanged (the result is nn.ConvTranspose2d's [Cin][Cout][4][4]); data gradient =
+    # the stride-2 convolution of g with the forward operand
+    if ops.fused_s2_ok(g.dtype, g.shape[3]):
+        ops.convkxk_wgrad(x, g, gw, 2, x_plain=True)
+        return ops.conv4x4s2(g, l.wf, None, l.conv_in) if need_dx else None
     gs = ops.space_to_depth_pad1_t(g)
-    ops.convkxk_wgrad(x, gs, gw, 2)              # roles exchanged: the result is nn.ConvTranspose2d's [Cin][Cout][4][4]
+    ops.convkxk_wgrad(x, gs, gw, 2)
     return ops.convkxk(gs, l.wf, None, l.conv_in, 2, 0) if need_dx else None
 
 
@@ -157,7 +171,7 @@ def _conv_s1_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, 
 
 @dataclass
 class _GCtx:
-    xs: List[torch.Tensor] = field(default_factory=list)        # space-to-depth input of every down layer
+    xs: List[torch.Tensor] = field(default_factory=list)        # what every down layer's weight gradient reads (its input)
     raw: List[Optional[torch.Tensor]] = field(default_factory=list)   # conv output ahead of a norm (None: no norm)
     act: List[torch.Tensor] = field(default_factory=list)       # down-layer activations a_i
     stats: List[Optional[torch.Tensor]] = field(default_factory=list)
@@ -226,20 +240,19 @@ class Pix2PixTrainer:
             ctx.cat[j] = torch.empty((B, H >> (i + 1), W >> (i + 1), 2 * ch[i]), dtype=dt, device=dev)
         x = ops.p2p_pack_input(src, None, torch.empty((B, H, W, 8), dtype=dt, device=dev))
         for i, l in enumerate(self.g_down):
-            xs = ops.space_to_depth_pad1_t(x)
-            ctx.xs.append(xs)
             skip = ctx.cat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
             if i == 0:                                    # LeakyReLU, no norm
-                a = _conv_s2_fwd(l, xs, act=True, slope=LRELU, out2=skip)
+                a, saved = _conv_s2_fwd(l, x, act=True, slope=LRELU, out2=skip)
                 ctx.raw.append(None); ctx.stats.append(None)
             elif i == n - 1:                              # innermost: ReLU, no norm
-                a = _conv_s2_fwd(l, xs, act=True, slope=0.0)
+                a, saved = _conv_s2_fwd(l, x, act=True, slope=0.0)
                 ctx.raw.append(None); ctx.stats.append(None)
             else:
-                raw = _conv_s2_fwd(l, xs)
+                raw, saved = _conv_s2_fwd(l, x)
                 a = torch.empty_like(raw)
                 ctx.stats.append(ops.instnorm_lrelu_fwd2(raw, LRELU, a, skip))
                 ctx.raw.append(raw)
+            ctx.xs.append(saved)
             ctx.act.append(a)
             x = a
         for j, l in enumerate(self.g_up):
@@ -294,14 +307,11 @@ class Pix2PixTrainer:
     def d_forward(self, d_in: torch.Tensor):
         """d_in [N,H,W,8] = [src | target-or-fake | 0 0] -> (logits [N,H/8-2,W/8-2,8] (channel 0), saved tensors)."""
         c1, c2, c3, c4, c5 = self.d_layers
-        xs1 = ops.space_to_depth_pad1_t(d_in)
-        a1 = _conv_s2_fwd(c1, xs1, act=True, slope=LRELU)
-        xs2 = ops.space_to_depth_pad1_t(a1)
-        r2 = _conv_s2_fwd(c2, xs2)
+        a1, xs1 = _conv_s2_fwd(c1, d_in, act=True, slope=LRELU)
+        r2, xs2 = _conv_s2_fwd(c2, a1)
         a2 = torch.empty_like(r2)
         s2 = ops.instnorm_lrelu_fwd2(r2, LRELU, a2)
-        xs3 = ops.space_to_depth_pad1_t(a2)
-        r3 = _conv_s2_fwd(c3, xs3)
+        r3, xs3 = _conv_s2_fwd(c3, a2)
         a3 = torch.empty_like(r3)
         s3 = ops.instnorm_lrelu_fwd2(r3, LRELU, a3)
         r4 = ops.convkxk(a3, c4.wf, c4.bias.detach(), c4.conv_out, 4, 1)

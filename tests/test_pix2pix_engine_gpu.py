@@ -32,7 +32,7 @@ def _l2(a, b):
 # kernels
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 24), (3, 8, 8, 64, 136), (1, 40, 32, 8, 64), (2, 8, 8, 256, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 24), (3, 8, 8, 64, 136), (1, 40, 32, 8, 64), (2, 8, 8, 256, 64), (2, 16, 16, 64, 128)])
 def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
     """The three layer kinds in both dtypes: forward, data gradient and weight gradient against torch's conv on the CPU
     (operands rounded to the storage dtype first, so the comparison sees the kernel and not the rounding of its inputs).
@@ -60,6 +60,16 @@ def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
     gw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
     ops.convkxk_wgrad(nhwc(gy), xs, gw, 2)
     assert relerr(gw, wr.grad) < tol
+    if ops.fused_s2_ok(dtype, cin):
+        # the layout-free bf16 kernels: plain input (space-to-depth in the loader), same results as the explicit form
+        skip2 = torch.zeros_like(skip)
+        y2 = ops.conv4x4s2(nhwc(x), wf, b.to(DEV), cout, act=True, slope=0.2, out2=skip2[..., :cout])
+        assert relerr(nchw(y2), ref) < tol and relerr(nchw(skip2[..., :cout]), torch.relu(ref)) < tol
+        gw2 = torch.empty_like(gw)
+        ops.convkxk_wgrad(nhwc(gy), nhwc(x), gw2, 2, x_plain=True)
+        assert relerr(gw2, wr.grad) < tol
+    if dtype == torch.bfloat16 and cin % 64 == 0:
+        assert relerr(nchw(ops.convT4x4s2(nhwc(gy), wd, None, cin)), xr.grad) < tol      # data gradient by phase
     # --- transposed, stride 2: weight [Cin][Cout][4][4], bias shared by the four sub-pixel groups ---
     wt, bt = rnd(cin, cout, 4, 4) * 0.1, rnd(cout)
     wf, wd = ops.pack_conv4x4_t(wt.to(DEV), 2, dtype)
@@ -74,6 +84,15 @@ def test_conv_s2_transposed_and_s1_against_torch(dtype, tol, shape):
     gw = torch.empty((cin, cout, 4, 4), dtype=torch.float32, device=DEV)
     ops.convkxk_wgrad(nhwc(x), gs, gw, 2)
     assert relerr(gw, wr.grad) < tol
+    if dtype == torch.bfloat16 and cout % 64 == 0:
+        wide = torch.zeros((B, 2 * H, 2 * W, 2 * cout), dtype=dtype, device=DEV)      # into a slice of a wider buffer
+        ops.convT4x4s2(nhwc(x), wd, bt.to(DEV), cout, out=wide[..., cout:])
+        assert relerr(nchw(wide[..., cout:]), ref) < tol and float(wide[..., :cout].abs().max()) == 0
+    if ops.fused_s2_ok(dtype, cout):
+        assert relerr(nchw(ops.conv4x4s2(nhwc(gy), wf, None, cin)), xr.grad) < tol
+        gw2 = torch.empty_like(gw)
+        ops.convkxk_wgrad(nhwc(x), nhwc(gy), gw2, 2, x_plain=True)
+        assert relerr(gw2, wr.grad) < tol
     # --- stride 1 ---
     wf, wd = ops.pack_conv4x4_t(w.to(DEV), 1, dtype)
     y1 = ops.convkxk(nhwc(x), wf, b.to(DEV), cout, 4, 1)
