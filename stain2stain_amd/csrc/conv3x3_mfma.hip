@@ -1644,6 +1644,23 @@ extern "C" int s2s_conv4x4s1_nhwc(int dtype, const void* x, int ldx, int cin, co
 //   (C % 64 == 0: narrower layers keep the space-to-depth form), by sub-pixel phase; wd = the data-gradient operand of
 //   s2s_pack_conv4x4 for the weight read as [O = Cin][C][4][4].  The same call is the data gradient of
 //   s2s_conv4x4s2_nhwc (x = dY, wd of the convolution's own weight, C = its input channels).
+// wide maps (W > 16): 0 = 8x32x128, 1 = 8x32x64, 2 = 4x32x128, 3 = 4x32x64; narrow: 4 = 8x16x128, 5 = 8x16x64.
+// The largest tile whose grid still fills the chip (two workgroups per CU) wins; `mult` = phases per tile.
+static int s2_tile(int B, int H, int W, int C, int mult, long* blocks) {
+  static const int th[6] = {8, 8, 4, 4, 8, 8}, tw[6] = {32, 32, 32, 32, 16, 16}, bn[6] = {128, 64, 128, 64, 128, 64};
+  const int first = W > 16 ? 0 : 4, last = W > 16 ? 4 : 6;
+  int best = first;
+  long bb = -1;
+  for (int i = first; i < last; ++i) {
+    if (bn[i] == 128 && C <= 64) continue;
+    const long nb = (long)mult * B * cdiv(H, th[i]) * cdiv(W, tw[i]) * cdiv(C, bn[i]);
+    if (nb >= 448) { best = i; bb = nb; break; }
+    if (nb > bb) { bb = nb; best = i; }
+  }
+  if (blocks) *blocks = bb;
+  return best;
+}
+
 static int s2_ksplit(long base, int nchunk) {
   if (base >= 192 || nchunk < 8) return 1;
   long sp = (512 + base - 1) / base;
@@ -1654,7 +1671,9 @@ static int s2_ksplit(long base, int nchunk) {
 
 extern "C" int s2s_conv4x4s2_ksplit(int B, int H, int W, int Cout, int Cin) {
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
-  return s2_ksplit((long)B * cdiv(H, 8) * cdiv(W, W > 16 ? 32 : 16) * cdiv(Cout, Cout > 64 ? 128 : 64), cdiv(4 * Cin, 32));
+  long base;
+  s2_tile(B, H, W, Cout, 1, &base);
+  return s2_ksplit(base, cdiv(4 * Cin, 32));
 }
 
 extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wf, const float* bias, void* y,
@@ -1676,10 +1695,15 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
   a.ksplit = kwork ? s2s_conv4x4s2_ksplit(B, H, W, Cout, Cin) : 1;
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool wide = W > 16, big = Cout > 64;
   int rc;
-  if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 0, 1>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 0, 1>(a, s);
-  else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 0, 1>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 0, 1>(a, s);
+  switch (s2_tile(B, H, W, Cout, 1, nullptr)) {
+    case 0: rc = launch_convkxk<8, 32, 128, 2, 2, 2, 0, 1>(a, s); break;
+    case 1: rc = launch_convkxk<8, 32, 64, 4, 1, 2, 0, 1>(a, s); break;
+    case 2: rc = launch_convkxk<4, 32, 128, 2, 2, 2, 0, 1>(a, s); break;
+    case 3: rc = launch_convkxk<4, 32, 64, 2, 2, 2, 0, 1>(a, s); break;
+    case 4: rc = launch_convkxk<8, 16, 128, 2, 2, 2, 0, 1>(a, s); break;
+    default: rc = launch_convkxk<8, 16, 64, 2, 2, 2, 0, 1>(a, s);
+  }
   if (rc != S2S_OK || !a.kpart) return rc;
   const long npix = (long)B * H * W, pieces = npix * (Cout / 8);
   long nb = (pieces + 255) / 256;
@@ -1691,7 +1715,9 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
 
 extern "C" int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin) {
   if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
-  return s2_ksplit(4L * B * cdiv(h, 8) * cdiv(w, w > 16 ? 32 : 16) * cdiv(C, C > 64 ? 128 : 64), cdiv(Cin, 32));
+  long base;
+  s2_tile(B, h, w, C, 4, &base);
+  return s2_ksplit(base, cdiv(Cin, 32));
 }
 
 extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wd, const float* bias, void* y,
@@ -1711,10 +1737,15 @@ extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, c
   a.ksplit = kwork ? s2s_convt4x4s2_ksplit(B, h, w, C, Cin) : 1;
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool wide = w > 16, big = C > 64;
   int rc;
-  if (wide) rc = big ? launch_convkxk<8, 32, 128, 2, 2, 2, 1, 2>(a, s) : launch_convkxk<8, 32, 64, 4, 1, 2, 1, 2>(a, s);
-  else rc = big ? launch_convkxk<8, 16, 128, 2, 2, 2, 1, 2>(a, s) : launch_convkxk<8, 16, 64, 2, 2, 2, 1, 2>(a, s);
+  switch (s2_tile(B, h, w, C, 4, nullptr)) {
+    case 0: rc = launch_convkxk<8, 32, 128, 2, 2, 2, 1, 2>(a, s); break;
+    case 1: rc = launch_convkxk<8, 32, 64, 4, 1, 2, 1, 2>(a, s); break;
+    case 2: rc = launch_convkxk<4, 32, 128, 2, 2, 2, 1, 2>(a, s); break;
+    case 3: rc = launch_convkxk<4, 32, 64, 2, 2, 2, 1, 2>(a, s); break;
+    case 4: rc = launch_convkxk<8, 16, 128, 2, 2, 2, 1, 2>(a, s); break;
+    default: rc = launch_convkxk<8, 16, 64, 2, 2, 2, 1, 2>(a, s);
+  }
   if (rc != S2S_OK || !a.kpart) return rc;
   const long npix = (long)B * 4 * h * w, pieces = npix * (C / 8);
   long nb = (pieces + 255) / 256;
