@@ -107,7 +107,8 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator, Pix2PixTrainer, ops
     torch.manual_seed(1984)
     G, D = Pix2PixGenerator().to(dev), PatchGANDiscriminator().to(dev)
-    tr = Pix2PixTrainer(G, D, lr=2e-4, betas=(0.5, 0.999), lambda_l1=100.0, precision=args.precision)
+    tr = Pix2PixTrainer(G, D, lr=2e-4, betas=(0.5, 0.999), lambda_l1=100.0, precision=args.precision,
+                        sharded_optimizer=args.sharded_optimizer)
     B = args.batch
     g = torch.Generator().manual_seed(1984 + rank)
     # four distinct synthetic batches rotate through the loop (a fixed batch would let the activations sparsify)
@@ -159,6 +160,9 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
                                "two fused Adam(2e-4, 0.5/0.999), D then G update; every launch a HIP kernel "
                                "(row a13: not in the reference, parity vs the torch-layer oracle)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "loss_d": round(ld, 5), "loss_g": round(lg, 4),
+                   "loss_bits": [float(v).hex() for v in losses.detach().cpu().tolist()],
+                   "grad_exchange": (tr.pG.bucketer.mode if tr.pG.bucketer.enabled else "none"),
+                   "buckets_mb": [round((hi - lo) * 4 / 2 ** 20, 2) for _, lo, hi in tr.pG.bucketer.buckets],
                    "algorithmic_gflop_per_step": round(step_flop / 1e9, 1),
                    "step_tflops": round(step_flop * steps / elapsed / 1e12, 1)},
         "roofline": {"bound": "mfma", "kernel": "convkxk_dma16_kernel (forward / data-gradient / transposed launches)",
@@ -181,6 +185,9 @@ def main() -> None:
     ap.add_argument("--tile", type=int, default=TILE, help="tile edge (default 256; 512 = BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pix2pix", action="store_true", help="skip the second timed loop (the pix2pix G + D step)")
+    ap.add_argument("--sharded-optimizer", action="store_true",
+                    help="gradient reduce-scatter + Adam on 1/world of every bucket + parameter all-gather instead of "
+                         "all-reduce + full Adam (same results; ddp.GradBucketer mode 'reduce_scatter')")
     ap.add_argument("--breakdown", action="store_true",
                     help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
     ap.add_argument("--event-every", type=int, default=8,
@@ -274,7 +281,7 @@ def main() -> None:
         if use_dist:
             dist.destroy_process_group()
         return
-    trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5)
+    trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5, sharded_optimizer=args.sharded_optimizer)
     g = torch.Generator().manual_seed(1984 + rank)
     B = args.batch
     # four distinct synthetic batches rotate through the loop (on one fixed batch the activations sparsify as training
@@ -385,7 +392,9 @@ def main() -> None:
             "config": {"workload": f"CFM U-Net [64,128,256,512,1024] 3x{TILE}x{TILE} H&E->IHC tiles, "
                                    f"batch {B}/GPU, sample+fwd+loss+bwd+allreduce+Adam",
                        "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
-                       "final_loss": round(float(loss), 6)},
+                       "final_loss": round(float(loss), 6), "loss_bits": float(loss).hex(),
+                       "grad_exchange": (trainer.bucketer.mode if trainer.bucketer.enabled else "none"),
+                       "buckets_mb": [round((hi - lo) * 4 / 2 ** 20, 2) for _, lo, hi in trainer.bucketer.buckets]},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,

@@ -1,16 +1,33 @@
-"""Data-parallel gradient exchange: one flat fp32 gradient buffer, bucketed all-reduce over RCCL.
+"""Data-parallel gradient exchange: one flat fp32 gradient buffer, bucketed collectives over RCCL.
 
 Replaces what Lightning's DDPStrategy + torch DDP do for the reference (``strategy: ddp``,
-configs/trainer/ddp.yaml:4): every rank holds a full replica and the only
-data-path collective is the gradient all-reduce (mean).  The flat buffer is laid out in the order in
-which the backward pass completes gradients (decoder head first, encoder stem last), so a bucket is a
-contiguous slice that becomes ready while earlier layers are still being differentiated;
-``mark_ready`` launches the all-reduce of every newly complete bucket asynchronously (on RCCL's own
-stream, ordered after the compute stream's work so far) and ``wait_all`` joins them before the
-optimiser step.  The averaging factor 1/world_size is folded into the Adam kernel's ``grad_scale``.
+configs/trainer/ddp.yaml:4): every rank holds a full replica, takes
+``batch_size // world_size`` tiles of every global batch (src/data/paired_data_module.py:273-278) and
+the only data-path collective is the gradient exchange (mean).  The flat buffer is laid out in the
+order in which the backward pass completes gradients (decoder head first, encoder stem last), one
+group per conv + norm LAYER, so a bucket is a contiguous slice that becomes ready while earlier
+layers are still being differentiated; ``mark_ready`` launches the collective of every newly
+complete bucket asynchronously (on RCCL's own stream, ordered after the compute stream's work so
+far) and ``wait_all`` joins them before the optimiser step.  The averaging factor 1/world_size is
+folded into the Adam kernel's ``grad_scale``.
+
+Bucket sizes are made for xGMI, not NVSwitch: a ring all-reduce on the 8 GPUs of a node is bound by one
+~153 GB/s link, so a bucket of b bytes occupies the wire for about 2 (7/8) b / 153 GB/s (0.18 ms at 16 MB).
+Buckets are therefore merged up to ``bucket_mb`` (small ones pay the ~20 us collective latency) and CAPPED at
+``max_bucket_mb``: the largest layers (1024 -> 1024, 38 MB; the 55 MB ``downs.3`` block of round 1) are cut
+into pieces, so that no single collective delays the ones queued behind it for more than ~0.2 ms.
+
+Two exchange modes:
+  * ``allreduce`` (default, what DDP does): every rank ends with the full summed gradient and runs the
+    whole fused Adam.
+  * ``reduce_scatter``: every bucket is reduce-scattered, a rank keeps 1/world of it, runs Adam on those
+    slices only (``shards()``) and the updated parameters are all-gathered (``all_gather``).  Same wire
+    volume as the ring all-reduce, 1/world of the optimiser pass (890 MB of HBM traffic per step for the
+    U-Net, 1.5 GB for the pix2pix generator) -- ZeRO-1 without the memory motive.
 
 Pure host logic over ``torch.distributed``: works with the ``nccl`` (= RCCL) backend on GPUs and with
-``gloo`` on CPU tensors, which is how tests/test_ddp_cpu.py exercises world_size = 2.
+``gloo`` on CPU tensors, which is how tests/test_ddp_cpu.py exercises world_size = 2 (gloo has no
+reduce-scatter: there the mode falls back to all-reduce + slice, same results).
 """
 from __future__ import annotations
 
@@ -20,57 +37,89 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+ALIGN = 64          # group starts are multiples of 64 floats: 8 ranks x 8-float (32-byte) shards
 
-def plan_buckets(group_sizes: Sequence[int], bucket_elems: int) -> List[Tuple[int, int, int]]:
-    """Merge consecutive parameter groups into buckets of at least ``bucket_elems`` elements.
 
-    Returns [(first_group, start_offset, end_offset)] with buckets covering [0, sum(group_sizes)); a
-    bucket is ready once all groups up to its last one are done, recorded as ``last_group`` in the
-    first slot of the following bucket minus one (see GradBucketer).
-    """
-    buckets = []
-    start, acc, first = 0, 0, 0
-    off = 0
+def plan_buckets(group_sizes: Sequence[int], bucket_elems: int, max_elems: Optional[int] = None,
+                 align: int = 1) -> List[Tuple[int, int, int]]:
+    """[(ready_group, start, end)]: consecutive parameter groups are merged until a bucket holds at least
+    ``bucket_elems`` elements; a bucket larger than ``max_elems`` is cut into equal pieces (multiples of ``align``)
+    that all become ready with the bucket's last group.  The buckets tile [0, sum(group_sizes))."""
+    merged = []
+    start, acc, off = 0, 0, 0
     for gi, n in enumerate(group_sizes):
         off += n
         acc += n
         if acc >= bucket_elems or gi == len(group_sizes) - 1:
-            buckets.append((gi, start, off))   # ready after group gi
+            merged.append((gi, start, off))   # ready after group gi
             start, acc = off, 0
-    return buckets
+    if not max_elems:
+        return merged
+    out = []
+    for gi, lo, hi in merged:
+        n = hi - lo
+        pieces = max(1, -(-n // max_elems))
+        step = -(-n // pieces)
+        step = -(-step // align) * align
+        a = lo
+        while a < hi:
+            b = min(hi, a + step)
+            out.append((gi, a, b))
+            a = b
+    return out
 
 
 class GradBucketer:
-    def __init__(self, flat_grad: torch.Tensor, group_sizes: Sequence[int], bucket_mb: float = 32.0,
-                 process_group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, flat_grad: torch.Tensor, group_sizes: Sequence[int], bucket_mb: float = 4.0,
+                 process_group: Optional[dist.ProcessGroup] = None, max_bucket_mb: Optional[float] = 16.0,
+                 mode: str = "allreduce"):
+        if mode not in ("allreduce", "reduce_scatter"):
+            raise ValueError("mode must be 'allreduce' or 'reduce_scatter'")
         self.flat = flat_grad
         self.pg = process_group
         # S2S_FORCE_DDP=1 issues the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
         self.enabled = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get("S2S_FORCE_DDP") == "1")
         self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self.rank = dist.get_rank(process_group) if self.enabled else 0
         if sum(group_sizes) != flat_grad.numel():
             raise ValueError("group sizes do not cover the flat gradient buffer")
-        self.buckets = plan_buckets(group_sizes, int(bucket_mb * (1 << 20) / flat_grad.element_size()))
+        es = flat_grad.element_size()
+        self.mode = mode
+        align = 8 * self.world if mode == "reduce_scatter" else 8
+        if mode == "reduce_scatter" and any(n % align for n in group_sizes):
+            raise ValueError(f"reduce_scatter mode needs parameter groups padded to multiples of {align} elements")
+        self.buckets = plan_buckets(group_sizes, int(bucket_mb * (1 << 20) / es),
+                                    int(max_bucket_mb * (1 << 20) / es) if max_bucket_mb else None, align)
+        self._native_rs = self.enabled and dist.get_backend(process_group) == "nccl"
         self._next = 0
         self._works: List = []
 
     @property
     def grad_scale(self) -> float:
-        """Factor that turns the all-reduced SUM into DDP's mean."""
+        """Factor that turns the exchanged SUM into DDP's mean."""
         return 1.0 / self.world
 
     def start_step(self) -> None:
         self._next = 0
         self._works = []
 
+    def _shard(self, lo: int, hi: int) -> Tuple[int, int]:
+        n = (hi - lo) // self.world
+        return lo + self.rank * n, lo + (self.rank + 1) * n
+
     def mark_ready(self, group_index: int) -> None:
-        """Groups 0..group_index have their gradients written (in stream order): reduce complete buckets."""
+        """Groups 0..group_index have their gradients written (in stream order): exchange complete buckets."""
         while self._next < len(self.buckets) and self.buckets[self._next][0] <= group_index:
             _, lo, hi = self.buckets[self._next]
             if self.enabled:
-                self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
-                                                   async_op=True))
+                if self.mode == "reduce_scatter" and self._native_rs:
+                    slo, shi = self._shard(lo, hi)      # in place: the output is this rank's slice of the input
+                    self._works.append(dist.reduce_scatter_tensor(self.flat[slo:shi], self.flat[lo:hi],
+                                                                  op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                else:
+                    self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
+                                                       async_op=True))
             self._next += 1
 
     def wait_all(self) -> None:
@@ -79,6 +128,30 @@ class GradBucketer:
         for w in self._works:
             w.wait()
         self._works = []
+
+    # ---- reduce_scatter mode: the slices this rank owns, and the parameter all-gather after its Adam pass ----
+    def shards(self) -> List[Tuple[int, int]]:
+        """[(start, end)] of the flat buffer this rank reduces and optimises (everything, in allreduce mode)."""
+        if self.mode != "reduce_scatter":
+            return [(0, self.flat.numel())]
+        return [self._shard(lo, hi) for _, lo, hi in self.buckets]
+
+    def all_gather(self, flat_param: torch.Tensor) -> None:
+        """After the sharded optimiser pass: every rank's slices of ``flat_param`` to every rank (blocking)."""
+        if self.mode != "reduce_scatter" or not self.enabled:
+            return
+        works = []
+        for _, lo, hi in self.buckets:
+            slo, shi = self._shard(lo, hi)
+            if self._native_rs:
+                works.append(dist.all_gather_into_tensor(flat_param[lo:hi], flat_param[slo:shi], group=self.pg,
+                                                         async_op=True))
+            else:       # gloo: list form
+                n = shi - slo
+                outs = [flat_param[lo + r * n: lo + (r + 1) * n] for r in range(self.world)]
+                works.append(dist.all_gather(outs, flat_param[slo:shi].clone(), group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
 
 
 def _active(process_group) -> bool:

@@ -209,8 +209,9 @@ def encoder_forward(blocks: Sequence[Tuple[ConvBN, ConvBN]], x_nchw: torch.Tenso
 def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeats: Sequence[Optional[torch.Tensor]],
                      grads: Dict[str, torch.Tensor], accumulate: bool = False, on_group_done=None) -> None:
     """dfeats[l]: gradient wrt level l's output activation (NHWC, or None); the max-pool path between the
-    levels is handled here.  ``on_group_done(k)`` fires after the k-th level (deepest first) has all its
-    parameter gradients enqueued -- the data-parallel bucketer hangs its all-reduce launches on it."""
+    levels is handled here.  ``on_group_done()`` fires after every conv + BatchNorm LAYER (deepest level first, second
+    conv of a level before its first) once its parameter gradients are enqueued -- the data-parallel bucketer hangs
+    its collective launches on it (trainer._param_groups lists the parameters in exactly this order)."""
     gpool = None
     nlev = len(blocks)
     for l in range(len(blocks) - 1, -1, -1):
@@ -220,9 +221,11 @@ def encoder_backward(blocks: Sequence[Tuple[ConvBN, ConvBN]], ctx: EncCtx, dfeat
         if g1 is None and gpool is None:
             raise RuntimeError("stain2stain_amd: encoder level without any incoming gradient")
         ga1 = _conv_bn_relu_bwd(c2, lc2, g1, gpool, grads, accumulate, need_dx=True)
+        if on_group_done is not None:
+            on_group_done()
         gpool = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=(l > 0), stem=(l == 0))
         if on_group_done is not None:
-            on_group_done(nlev - 1 - l)
+            on_group_done()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -260,31 +263,34 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
                      accumulate: bool = False, need_dt_emb: bool = False, on_group_done=None,
                      g_head: Optional[torch.Tensor] = None):
     """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype.
-    ``on_group_done(k)``: k = 0 after the head, 1.. after each Up block (last block first), then the time path."""
+    ``on_group_done()``: after the head, after every conv + BatchNorm layer (last Up block first, its second conv before
+    its first), then after the time path."""
     if g_head is not None:      # head gradients already produced by the fused head+loss kernel
         g = g_head
     else:
         g = ops.head_bwd(dv, ctx.lows[-1], dec.outc.weight.detach(), _g(grads, "outc.weight"),
                          _g(grads, "outc.bias") if dec.outc.bias is not None else None, accumulate)
     if on_group_done is not None:
-        on_group_done(0)
+        on_group_done()
     nup = len(ctx.layers)
     dskips: List[torch.Tensor] = [None] * len(ctx.layers)
     for i in range(len(ctx.layers) - 1, -1, -1):
         c1, c2 = dec.up_blocks[i]
         lc1, lc2 = ctx.layers[i]
         ga1 = _conv_bn_relu_bwd(c2, lc2, g, None, grads, accumulate, need_dx=True)
+        if on_group_done is not None:
+            on_group_done()
         dcat = _conv_bn_relu_bwd(c1, lc1, ga1, None, grads, accumulate, need_dx=True)
         cs = ctx.skips[i].shape[3]
         dskips[i] = dcat[..., :cs]
         low = ctx.lows[i]
         g = ops.upsample2x_bwd(dcat[..., cs:], low.shape[1], low.shape[2])
         if on_group_done is not None:
-            on_group_done(nup - i)
+            on_group_done()
     dbott = g
     if getattr(dec, "time_mlp", None) is None:
         if on_group_done is not None:
-            on_group_done(nup + 1)
+            on_group_done()
         return dbott, dskips, None
     # time path: tbias was broadcast-added to the bottleneck before the first up-sampling
     dtb = ops.pixel_sum(g)
@@ -297,5 +303,5 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
     dt_emb = ops.linear_bwd(dh1, ctx.t_emb, l0.weight.detach(), _g(grads, "time_mlp.0.weight"),
                             _g(grads, "time_mlp.0.bias"), need_dt_emb, accumulate)
     if on_group_done is not None:
-        on_group_done(nup + 1)
+        on_group_done()
     return dbott, dskips, dt_emb

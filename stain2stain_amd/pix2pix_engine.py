@@ -30,7 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .ddp import GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
+from .ddp import ALIGN, GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
 from .pix2pix import PatchGANDiscriminator, Pix2PixGenerator
 
 LRELU = 0.2
@@ -41,7 +41,8 @@ class FlatParams:
 
     ``groups``: [[(name, parameter), ...], ...] in the order the backward pass completes them."""
 
-    def __init__(self, groups: List[List[Tuple[str, torch.nn.Parameter]]], bucket_mb: float, process_group):
+    def __init__(self, groups: List[List[Tuple[str, torch.nn.Parameter]]], bucket_mb: float, process_group,
+                 max_bucket_mb: float = 16.0, sharded: bool = False):
         dev = groups[0][0][1].device
         sizes, offs, off = [], {}, 0
         for g in groups:
@@ -49,6 +50,7 @@ class FlatParams:
             for name, p in g:
                 offs[name] = off
                 off += (p.numel() + 7) // 8 * 8            # 32-byte aligned views
+            off = (off + ALIGN - 1) // ALIGN * ALIGN       # groups (layers) divide into aligned shards for <= 8 ranks
             sizes.append(off - start)
         self.p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.g = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -65,15 +67,18 @@ class FlatParams:
                     p.grad = self.g[o:o + n].view(p.shape)
                     self.grads[name] = p.grad
                     self.slot[name] = (o, n)
-        self.bucketer = GradBucketer(self.g, sizes, bucket_mb, process_group)
+        self.bucketer = GradBucketer(self.g, sizes, bucket_mb, process_group, max_bucket_mb,
+                                     "reduce_scatter" if sharded else "allreduce")
         self.step_count = 0
         broadcast_from_rank0([self.p], process_group)
 
     def adam(self, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float) -> None:
         self.bucketer.wait_all()
         self.step_count += 1
-        ops.adam_step_(self.p, self.g, self.m, self.v, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
-                       self.bucketer.grad_scale)
+        for lo, hi in self.bucketer.shards():              # everything, or this rank's slices in sharded mode
+            ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.step_count, lr, betas[0],
+                           betas[1], eps, weight_decay, self.bucketer.grad_scale)
+        self.bucketer.all_gather(self.p)
 
 
 @dataclass
@@ -190,8 +195,8 @@ class Pix2PixTrainer:
 
     def __init__(self, G: Pix2PixGenerator, D: PatchGANDiscriminator, lr: float = 2e-4,
                  betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 lambda_l1: float = 100.0, precision: str = "bf16", bucket_mb: float = 16.0, process_group=None,
-                 sync_loss: bool = True):
+                 lambda_l1: float = 100.0, precision: str = "bf16", bucket_mb: float = 4.0, process_group=None,
+                 sync_loss: bool = True, max_bucket_mb: float = 16.0, sharded_optimizer: bool = False):
         dev = next(G.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: Pix2PixTrainer needs the networks on a GPU (HIP-only implementation)")
@@ -214,8 +219,9 @@ class Pix2PixTrainer:
 
         # backward-completion order: last up layer first ... first down layer last; D: c5 ... c1
         self.pG = FlatParams([group(l) for l in reversed(self.g_up)] + [group(l) for l in reversed(self.g_down)],
-                             bucket_mb, process_group)
-        self.pD = FlatParams([group(l) for l in reversed(self.d_layers)], bucket_mb, process_group)
+                             bucket_mb, process_group, max_bucket_mb, sharded_optimizer)
+        self.pD = FlatParams([group(l) for l in reversed(self.d_layers)], bucket_mb, process_group, max_bucket_mb,
+                             sharded_optimizer)
         self.packG = _Packer(self.g_down + self.g_up, self.dtype)
         self.packD = _Packer(self.d_layers, self.dtype)
         self.in_channels, self.out_channels = G.in_channels, G.out_channels
@@ -357,13 +363,13 @@ class Pix2PixTrainer:
         """One G + D evaluation.  ``update=True`` is the training step (D is updated before the generator's pass through
         it, as in pix2pix_step); ``update=False`` leaves both networks untouched and evaluates the two losses and both
         gradient sets at the CURRENT parameters (what ``(loss_D + loss_G).backward()`` of pix2pix_losses yields), for the
-        parity tests.  Returns (losses, fake): ``losses`` = device float[6] {BCE(D(real), 1), BCE(D(fake), 0),
-        BCE(D(fake), 1), 0, L1(fake, tgt), 0} (no host synchronisation; ``loss_values`` turns it into loss_D / loss_G),
+        parity tests.  Returns (losses, fake): ``losses`` = device float[8] {BCE(D(real), 1), BCE(D(fake), 0),
+        BCE(D(fake), 1), 0, L1(fake, tgt), 0, 0, 0} (no host synchronisation; ``loss_values`` turns it into loss_D / loss_G),
         ``fake`` = NCHW fp32 or None."""
         B, C, H, W = tgt.shape
         dev, dt = src.device, self.dtype
         src, tgt = src.contiguous().float(), tgt.contiguous().float()
-        losses = torch.empty((6,), dtype=torch.float32, device=dev)
+        losses = torch.zeros((8,), dtype=torch.float32, device=dev)
         gctx = self.g_forward(src)
         d_in = torch.empty((2 * B, H, W, 8), dtype=dt, device=dev)          # [real pairs | fake pairs]
         ops.p2p_pack_input(src, tgt, d_in[:B])

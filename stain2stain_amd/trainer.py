@@ -21,11 +21,13 @@ import torch.distributed as dist
 
 from . import engine, ops
 from .components import FlowUNet
-from .ddp import GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
+from .ddp import ALIGN, GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
 
 
 def _param_groups(net: FlowUNet) -> List[List[Tuple[str, str, torch.nn.Parameter]]]:
-    """Parameters grouped in the order the backward pass finishes them.
+    """Parameters grouped in the order the backward pass finishes them, one group per conv + BatchNorm LAYER
+    (engine.decoder_backward / encoder_backward fire ``on_group_done`` in exactly this order): the head, every Up
+    block from the last (its second conv before its first), the time MLP, every encoder level from the deepest.
 
     Each entry is (owner, local_name, parameter) with owner in {"dec", "enc"}.
     """
@@ -33,15 +35,22 @@ def _param_groups(net: FlowUNet) -> List[List[Tuple[str, str, torch.nn.Parameter
     dnamed = dict(dec.named_parameters())
     enamed = dict(enc.named_parameters())
     groups: List[List[Tuple[str, str, torch.nn.Parameter]]] = []
+
+    def layer(owner, named, prefix):        # the two layers of a DoubleConv: (conv 3, bn 4) finishes before (conv 0, bn 1)
+        for idx in (("3.", "4."), ("0.", "1.")):
+            groups.append([(owner, n, p) for n, p in named.items()
+                           if any(n.startswith(prefix + i) for i in idx)])
+
     groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith("outc.")])
     for i in range(len(dec.ups) - 1, -1, -1):
-        groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith(f"ups.{i}.")])
+        layer("dec", dnamed, f"ups.{i}.conv.double_conv.")
     groups.append([("dec", n, p) for n, p in dnamed.items() if n.startswith("time_")])
     for i in range(len(enc.downs) - 1, -1, -1):
-        groups.append([("enc", n, p) for n, p in enamed.items() if n.startswith(f"downs.{i}.")])
-    groups.append([("enc", n, p) for n, p in enamed.items() if n.startswith("inc.")])
+        layer("enc", enamed, f"downs.{i}.maxpool_conv.1.double_conv.")
+    layer("enc", enamed, "inc.double_conv.")
+    groups = [g for g in groups if g] if getattr(dec, "time_mlp", None) is None else groups
     seen = sum(len(g) for g in groups)
-    if seen != len(dnamed) + len(enamed):
+    if seen != len(dnamed) + len(enamed) or any(not g for g in groups):
         raise RuntimeError("parameter grouping does not cover the network")
     return groups
 
@@ -80,7 +89,11 @@ class FusedAdamHandle(torch.optim.Optimizer):
 class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
-                 bucket_mb: float = 4.0, process_group=None, sync_loss: bool = True):
+                 bucket_mb: float = 4.0, process_group=None, sync_loss: bool = True, max_bucket_mb: float = 16.0,
+                 sharded_optimizer: bool = False):
+        """``sharded_optimizer``: exchange gradients by reduce-scatter, run the fused Adam on this rank's 1/world of every
+        bucket and all-gather the updated parameters (ddp.GradBucketer, mode "reduce_scatter") instead of all-reduce +
+        a full Adam pass on every rank.  Same results, same wire volume, 1/world of the optimiser's HBM traffic."""
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: CFMTrainer needs the network on a GPU (HIP-only implementation)")
@@ -90,13 +103,15 @@ class CFMTrainer:
         self.sync_loss = sync_loss
         self.step_count = 0
         groups = _param_groups(net)
-        # 8-float alignment of every parameter keeps the flat views 32-byte aligned
+        # 8-float alignment of every parameter keeps the flat views 32-byte aligned; groups (= layers) start on
+        # multiples of ddp.ALIGN floats so that a bucket divides into 32-byte-aligned shards for up to 8 ranks
         sizes, offs, off = [], {}, 0
         for g in groups:
             start = off
             for owner, name, p in g:
                 offs[(owner, name)] = off
                 off += (p.numel() + 7) // 8 * 8
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
             sizes.append(off - start)
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -116,8 +131,9 @@ class CFMTrainer:
         self._slot = {id(p): (offs[(owner, name)], p.numel()) for g in groups for owner, name, p in g}
         self.optimizer = FusedAdamHandle(self, lr, betas, eps, weight_decay)
         self.n_params = sum(p.numel() for g in groups for _, _, p in g)
-        self.n_dec_groups = 2 + len(net.flow_decoder.ups)
-        self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group)
+        self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group, max_bucket_mb,
+                                     "reduce_scatter" if sharded_optimizer else "allreduce")
+        self._group = 0
         broadcast_from_rank0([self.flat_p] + [b for b in net.buffers()], process_group)
         self._blocks = list(net.encoder._blocks) + list(net.flow_decoder.up_blocks)
         # one launch re-packs every MFMA conv's weights (all but the stem, which reads the fp32 master directly)
@@ -166,20 +182,27 @@ class CFMTrainer:
                                               want_v=want_v)
         dctx.v = v
         self.bucketer.start_step()
-        nd = self.n_dec_groups
+        self._group = 0
         dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
-                                                   on_group_done=lambda k: self.bucketer.mark_ready(k))
+                                                   on_group_done=self._group_done)
         L = len(feats) - 1
         dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
-        engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc,
-                                on_group_done=lambda k: self.bucketer.mark_ready(nd + k))
+        engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
         return loss, dctx.v
+
+    def _group_done(self) -> None:
+        """The next parameter group (layer, in _param_groups order) has its gradients enqueued."""
+        self.bucketer.mark_ready(self._group)
+        self._group += 1
 
     def optimizer_step(self) -> None:
         self.bucketer.wait_all()
         self.step_count += 1
-        ops.adam_step_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas[0],
-                       self.betas[1], self.eps, self.wd, self.bucketer.grad_scale)
+        for lo, hi in self.bucketer.shards():          # everything, or this rank's slices in sharded mode
+            ops.adam_step_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                           self.bucketer.grad_scale)
+        self.bucketer.all_gather(self.flat_p)
         engine.mutation_epoch[0] += 1
         self._repack()              # master weights changed behind torch's version counter
 

@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", *extra],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _run(*extra, env=None, steps=2):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=None if env is None else {**os.environ, **env})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout
@@ -25,6 +26,9 @@ def test_training_line_has_the_contract_keys():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    # BASELINE.json's metric is worded on the pix2pix G + D step: the driver's line carries it under its own key
+    p = d["pix2pix"]
+    assert "pix2pix" in p["metric"] and p["unit"] == "tiles/s" and p["value"] > 100 and p["roofline"]["bound"] == "mfma"
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["unit"] == "tiles/s"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
@@ -46,3 +50,21 @@ def test_pix2pix_line():
     assert d["unit"] == "tiles/s" and "pix2pix" in d["metric"] and d["n_gpus"] == 1 and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 10
     assert d["config"]["loss_d"] == d["config"]["loss_d"] and d["config"]["loss_g"] == d["config"]["loss_g"]   # finite
+
+
+def test_rccl_path_in_a_fresh_process_matches_the_single_process_run():
+    """the gradient exchange has to run over RCCL somewhere in the GPU suite.  A fresh child process
+    runs bench.py with S2S_FORCE_DDP=1 (process group "nccl" = RCCL at world size 1: bucketed all-reduce on RCCL's
+    stream, joined before Adam, 1/world folded into the update) and its final losses -- CFM step and pix2pix G + D step --
+    must equal the run without any collective BIT FOR BIT; the reduce-scatter / sharded-Adam / all-gather mode as well."""
+    port = {"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    plain = _run("--no-cpu-baseline", steps=3)
+    ddp = _run("--no-cpu-baseline", steps=3, env={"S2S_FORCE_DDP": "1", "MASTER_PORT": "29611", **port})
+    rs = _run("--no-cpu-baseline", "--sharded-optimizer", steps=3, env={"S2S_FORCE_DDP": "1", "MASTER_PORT": "29612", **port})
+    assert plain["config"]["grad_exchange"] == "none" and ddp["config"]["grad_exchange"] == "allreduce"
+    assert rs["config"]["grad_exchange"] == "reduce_scatter"
+    assert max(ddp["config"]["buckets_mb"]) <= 16.0 and len(ddp["config"]["buckets_mb"]) == 14
+    for other in (ddp, rs):
+        assert other["config"]["loss_bits"] == plain["config"]["loss_bits"]
+        assert other["pix2pix"]["config"]["loss_bits"] == plain["pix2pix"]["config"]["loss_bits"]
+    assert ddp["pix2pix"]["config"]["grad_exchange"] == "allreduce" and max(ddp["pix2pix"]["config"]["buckets_mb"]) <= 16.0
