@@ -197,6 +197,8 @@ def main() -> None:
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
     ap.add_argument("--euler-steps", type=int, default=50)
+    ap.add_argument("--graph", action="store_true",
+                    help="--mode sample: replay one hipGraph-captured Euler step instead of launching its ~60 kernels")
     ap.add_argument("--h2d", action="store_true",
                     help="PCIe-inclusive variant for DESIGN.md: every step copies a fresh uint8 batch from pinned host "
                          "memory and runs the GPU crop/flip/normalise kernel before the optimisation step")
@@ -235,7 +237,7 @@ def main() -> None:
         src = (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev)
         net.eval()
         for _ in range(max(1, args.warmup // 3)):
-            euler_generate(net, src, args.euler_steps)
+            euler_generate(net, src, args.euler_steps, graph=args.graph)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -243,10 +245,10 @@ def main() -> None:
         prof, timed_steps = [], 0
         t0 = time.perf_counter()
         for i in range(args.steps):
-            sampled = i % max(1, args.event_every) == 0       # see the note in the training loop below
+            sampled = i % max(1, args.event_every) == 0 and not args.graph     # (no event brackets inside a graph)
             if sampled:
                 ops.profile_start(("conv3x3_mfma",))
-            out = euler_generate(net, src, args.euler_steps)
+            out = euler_generate(net, src, args.euler_steps, graph=args.graph)
             if sampled:
                 prof += ops.profile_stop()
                 timed_steps += 1
@@ -260,9 +262,10 @@ def main() -> None:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             elapsed = float(el)
         if rank == 0:
-            n_l = len(prof)
-            t_l = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
+            n_l = max(len(prof), 1)
+            t_l = max(sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3, 1e-12)
             f_l = sum(w for _, w, _, _ in prof)
+            timed_steps = max(timed_steps, 1)
             _emit(json.dumps({
                 "metric": f"256x256 tiles/sec sampled ({args.euler_steps} Euler steps, eval-mode network)",
                 "value": round(B * world * args.steps / elapsed, 3), "unit": "tiles/s", "n_gpus": world,
@@ -270,7 +273,9 @@ def main() -> None:
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                 "data": "synthetic",
                 "config": {"workload": f"CFM U-Net {FEATURES} 3x256x256, batch {B}/GPU, {args.euler_steps} Euler "
-                                       "steps (BatchNorm folded into the conv epilogue)",
+                                       "steps (BatchNorm folded into the conv epilogue)"
+                                       + (", one hipGraph replay per step" if args.graph else ", eager launches"),
+                           "ms_per_euler_step": round(elapsed * 1e3 / args.steps / args.euler_steps, 4),
                            "global_batch": B * world, "parallelism": f"replicas x{world}",
                            "finite": bool(torch.isfinite(out).all())},
                 "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (forward launches)",

@@ -147,6 +147,9 @@ int s2s_ode_error_norm(const float* e, const float* y0, const float* y1, float a
                        double* work, long n, void* stream);
 int s2s_axpy(float* x, const float* y, float a, long n, void* stream);
 int s2s_fill_f32(float* x, float v, long n, void* stream);
+/* t[0..n) <- table[*counter], then *counter += 1: the time input of a hipGraph-captured Euler step (the captured
+ * kernel walks a table of the node times, so a replay needs no host-side argument). */
+int s2s_euler_tick(float* t, int n, const float* table, int* counter, void* stream);
 
 /* ---- optimiser, packing, layout (optim.hip) ------------------------------------------------------ */
 /* torch.optim.Adam step over a flat fp32 buffer (configs/model/*.yaml:3-7) */

@@ -9,7 +9,7 @@ from .components import (ClassConditionalFlowUNet, FlowMatchingDecoder, FlowUNet
 from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowMatcher,
                             ConditionalFlowMatchingModule, MaskConditionedFlowMatchingModule,
                             MultiTaskFlowMatchingModule, ROICharbonnierFlowMatchingModule,
-                            ROIWeightedFlowMatchingModule, SolverConfig, dopri5_generate, dopri5_integrate,
+                            GraphedVelocity, ROIWeightedFlowMatchingModule, SolverConfig, dopri5_generate, dopri5_integrate,
                             euler_generate, euler_integrate)
 from . import checkpoint
 from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU,
@@ -18,7 +18,7 @@ from .pix2pix_engine import Pix2PixTrainer
 from .trainer import CFMTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
-           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate", "euler_integrate", "dopri5_integrate", "SolverConfig",
+           "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate", "euler_integrate", "dopri5_integrate", "SolverConfig", "GraphedVelocity",
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",

@@ -293,6 +293,24 @@ extern "C" int s2s_axpy(float* x, const float* y, float a, long n, void* stream)
   return S2S_OK;
 }
 
+// t[0..n) <- table[*counter]; *counter += 1.  The time input of a graph-captured Euler step: the node times t_k =
+// k / num_steps are tabulated on the host exactly as the eager loop computes them, and the captured kernel walks the table.
+__global__ void euler_tick_kernel(float* __restrict__ t, int n, const float* __restrict__ table, int* __restrict__ counter) {
+  const int k = *counter;
+  const float v = table[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = v;
+  if (threadIdx.x == 0) *counter = k + 1;
+}
+
+extern "C" int s2s_euler_tick(float* t, int n, const float* table, int* counter, void* stream) {
+  if (!t || !table || !counter) return S2S_ERR_NULL;
+  if (n <= 0) return S2S_ERR_SHAPE;
+  hipLaunchKernelGGL(euler_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, n, table, counter);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 extern "C" int s2s_fill_f32(float* x, float v, long n, void* stream) {
   if (!x) return S2S_ERR_NULL;
   if (n <= 0) return S2S_ERR_SHAPE;

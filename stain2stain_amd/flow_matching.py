@@ -96,10 +96,93 @@ def euler_integrate(f, x: torch.Tensor, num_steps: int) -> torch.Tensor:
 
 
 @torch.no_grad()
-def euler_generate(net, source_img: torch.Tensor, num_steps: int = 50) -> torch.Tensor:
-    """x(0) = source, x <- x + v(t_k, x)/n at t_k = k/n, network in eval mode (its mode is restored); returns x(1)."""
+def euler_generate(net, source_img: torch.Tensor, num_steps: int = 50, graph: bool = False) -> torch.Tensor:
+    """x(0) = source, x <- x + v(t_k, x)/n at t_k = k/n, network in eval mode (its mode is restored); returns x(1).
+    ``graph=True`` replays one captured Euler step ``num_steps`` times (GraphedVelocity; cached on the network until its
+    parameters, the batch shape or the step size change): same kernels, same results, no per-kernel launch cost."""
     with _eval_mode(net):
-        return euler_integrate(net, _prep_source(source_img), num_steps)
+        x = _prep_source(source_img)
+        if not graph:
+            return euler_integrate(net, x, num_steps)
+        dt = 1.0 / num_steps
+        g = getattr(net, "_s2s_euler_graph", None)
+        if g is None or not g.matches(net, x, dt):
+            g = GraphedVelocity(net, x, dt)
+            try:
+                object.__setattr__(net, "_s2s_euler_graph", g)      # a plain attribute, not a registered sub-module
+            except Exception:  # noqa: BLE001 -- a callable that takes no attributes: rebuild next time
+                pass
+        return g.solve_euler(x, num_steps)
+
+
+class GraphedVelocity:
+    """``v = net(t, x)`` as a replayed hipGraph (one ``hipGraphLaunch`` per evaluation instead of ~60 kernel launches).
+
+    The reference samples ONE tile at a time (src/infer_simple_flowmatching.py:73-83); at batch 1 the eval-mode forward
+    is ~60 short kernels and the eager path is bound by host launch time (~2.3 ms of launches per evaluation, round-1
+    measurement).  Everything the forward touches has a fixed address inside the capture (torch's graph-private memory
+    pool owns the intermediates; weights, packed operands and folded BatchNorm constants are warmed up before capture),
+    so a replay recomputes the same kernels on whatever ``t`` / ``x`` currently hold.
+
+    With ``dt`` the capture is a whole Euler step -- ``t <- t_k`` (device-side table walk), ``v``, ``x += dt * v``: a whole fixed-step solve is then ``num_steps``
+    graph launches and nothing else.  The network must be in eval mode and its parameters must not change while the
+    graph is alive (``GraphedVelocity.matches`` tells a cache when to rebuild)."""
+
+    def __init__(self, net, x_like: torch.Tensor, dt: Optional[float] = None):
+        if not x_like.is_cuda:
+            raise RuntimeError("stain2stain_amd: GraphedVelocity needs GPU tensors (there is no CPU path)")
+        from . import engine
+        B = x_like.shape[0]
+        self.net, self.dt = net, dt
+        self.key = (tuple(x_like.shape), dt, engine.mutation_epoch[0], tuple(p._version for p in _params(net)))
+        self.x = x_like.detach().float().contiguous().clone()
+        self.t = torch.zeros((B,), dtype=torch.float32, device=x_like.device)
+        if dt is not None:
+            # node times exactly as the eager loop forms them (k * dt in double, rounded once); the captured step
+            # reads table[counter] and advances the counter on the device
+            n = int(round(1.0 / dt))
+            self._table = torch.tensor([k * dt for k in range(n + 2)], dtype=torch.float32, device=x_like.device)
+            self._counter = torch.zeros((1,), dtype=torch.int32, device=x_like.device)
+        side = torch.cuda.Stream(device=x_like.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # warm-up: packed weights, folded BN constants, LDS attributes
+            for _ in range(2):
+                net(self.t, self.x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            if dt is not None:
+                ops.euler_tick_(self.t, self._table, self._counter)
+            self.v = net(self.t, self.x).contiguous()
+            if dt is not None:
+                ops.axpy_(self.x, self.v, dt)
+
+    def matches(self, net, x: torch.Tensor, dt: Optional[float]) -> bool:
+        from . import engine
+        return net is self.net and self.key == (tuple(x.shape), dt, engine.mutation_epoch[0],
+                                                tuple(p._version for p in _params(net)))
+
+    def __call__(self, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """v(t, x): copies the arguments into the graph's buffers, replays, returns the graph's output buffer (valid
+        until the next call)."""
+        self.x.copy_(x)
+        self.t.copy_(t.to(torch.float32).expand(self.t.shape[0]) if t.dim() <= 1 and t.numel() == 1 else t)
+        self.graph.replay()
+        return self.v
+
+    def solve_euler(self, source: torch.Tensor, num_steps: int) -> torch.Tensor:
+        if self.dt is None or abs(self.dt * num_steps - 1.0) > 1e-9:
+            raise ValueError("this graph was captured for a different step size")
+        self.x.copy_(source)
+        self._counter.zero_()
+        for _ in range(num_steps):
+            self.graph.replay()
+        return self.x.clone()
+
+
+def _params(net):
+    return list(net.parameters()) if isinstance(net, torch.nn.Module) else []
 
 
 # Dormand-Prince 5(4): nodes, stage matrix (row 7 = the 5th-order weights, first-same-as-last) and error weights
@@ -116,10 +199,15 @@ _DP_E = (-71 / 57600, 0.0, 71 / 16695, -71 / 1920, 17253 / 339200, -22 / 525, 1 
 
 @torch.no_grad()
 def dopri5_generate(net, source_img: torch.Tensor, atol: float = 1e-4, rtol: float = 1e-4, max_steps: int = 1000,
-                    return_stats: bool = False):
-    """``dopri5_integrate`` on a network put in eval mode for the solve (mode restored, also when it raises)."""
+                    return_stats: bool = False, graph: bool = False):
+    """``dopri5_integrate`` on a network put in eval mode for the solve (mode restored, also when it raises).
+    ``graph=True``: every stage evaluation is a replay of one captured forward (GraphedVelocity)."""
     with _eval_mode(net):
-        return dopri5_integrate(net, _prep_source(source_img), atol, rtol, max_steps, return_stats)
+        x = _prep_source(source_img)
+        if not graph:
+            return dopri5_integrate(net, x, atol, rtol, max_steps, return_stats)
+        gv = GraphedVelocity(net, x, None)
+        return dopri5_integrate(lambda t, y: gv(t, y).clone(), x, atol, rtol, max_steps, return_stats)
 
 
 @torch.no_grad()
@@ -211,7 +299,7 @@ def _solver_setting(solver, name: str, default):
 
 
 def _solve(module, f, source_img: torch.Tensor, num_steps: int, method: Optional[str], atol: Optional[float],
-           rtol: Optional[float]) -> torch.Tensor:
+           rtol: Optional[float], graph: bool = False) -> torch.Tensor:
     """The ODE solve shared by every ``generate``: like the reference it refuses to run without a solver, puts the
     module in eval mode and LEAVES it there (``self.eval()``, conditional_flow_matching.py:147-150), integrates with
     the solver's method / tolerances (dopri5, 1e-4 when it names none) and returns the end point x(1).  ``method``
@@ -224,8 +312,13 @@ def _solve(module, f, source_img: torch.Tensor, num_steps: int, method: Optional
     rtol = _solver_setting(module.solver, "rtol", 1e-4) if rtol is None else rtol
     x = _prep_source(source_img)
     if method == "dopri5":
+        if graph:           # every stage evaluation = one replay of the captured forward
+            gv = GraphedVelocity(f, x, None)
+            return dopri5_integrate(lambda t, y: gv(t, y).clone(), x, atol, rtol)
         return dopri5_integrate(f, x, atol, rtol)
     if method == "euler":
+        if graph:
+            return GraphedVelocity(f, x, 1.0 / num_steps).solve_euler(x, num_steps)
         return euler_integrate(f, x, num_steps)
     raise ValueError(f"solver method must be 'dopri5' or 'euler', got {method!r}")
 
@@ -272,12 +365,14 @@ class ConditionalFlowMatchingModule(_Base):
 
     @torch.no_grad()
     def generate(self, source_img: torch.Tensor, num_steps: int = 100, method: Optional[str] = None,
-                 atol: Optional[float] = None, rtol: Optional[float] = None) -> torch.Tensor:
+                 atol: Optional[float] = None, rtol: Optional[float] = None, graph: bool = False) -> torch.Tensor:
         """x(1) of dx/dt = net(t, x), x(0) = source (conditional_flow_matching.py:133-170): the solver's method --
         adaptive dopri5 at atol = rtol = 1e-4 unless ``self.solver`` says otherwise; ``num_steps`` only defined the
         reference's output grid and plays no role for the end point -- or, with ``method="euler"``, ``num_steps``
-        fixed Euler steps.  Raises without a solver and leaves the module in eval mode, as the reference does."""
-        return _solve(self, self.net, source_img, num_steps, method, atol, rtol)
+        fixed Euler steps.  Raises without a solver and leaves the module in eval mode, as the reference does.
+        ``graph=True`` replays the network evaluation as a captured hipGraph (the reference samples one tile at a time,
+        infer_simple_flowmatching.py:73-83, where the eager path is launch-bound)."""
+        return _solve(self, self.net, source_img, num_steps, method, atol, rtol, graph)
 
 
 class _WeightedMSE(torch.autograd.Function):

@@ -530,6 +530,13 @@ def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> None:
     _native.check(_L().s2s_axpy(_f32(x), _f32(y), float(a), x.numel(), _stream()), "axpy")
 
 
+def euler_tick_(t: torch.Tensor, table: torch.Tensor, counter: torch.Tensor) -> None:
+    """t[:] = table[counter]; counter += 1 (device side; see s2s_euler_tick)."""
+    if counter.dtype != torch.int32 or table.dtype != torch.float32:
+        raise RuntimeError("stain2stain_amd: euler_tick wants an int32 counter and a float32 table")
+    _native.check(_L().s2s_euler_tick(_f32(t), t.numel(), _f32(table), counter.data_ptr(), _stream()), "euler_tick")
+
+
 def fill_(x: torch.Tensor, v: float) -> None:
     _native.check(_L().s2s_fill_f32(_f32(x), float(v), x.numel(), _stream()), "fill")
 

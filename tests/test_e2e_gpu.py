@@ -335,3 +335,33 @@ def test_optimizer_handle_checkpoints_the_adam_state():
         tr_b.step(x0, x1, t)
     for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_graph_captured_sampler_equals_the_eager_one(golden_tiny):
+    """the Euler solve and the dopri5 stage evaluations as replayed hipGraphs.  Same kernels in the
+    same order on the same data, so the results equal the eager path bit for bit; batch 1 as in the reference's
+    sampling script (src/infer_simple_flowmatching.py:73-83).  The golden Euler end point still holds through the
+    graph; a parameter change invalidates the cached capture."""
+    from stain2stain_amd import ConditionalFlowMatchingModule, SolverConfig, dopri5_generate, euler_generate
+    G = golden_tiny
+    net = build_net(G, "fp32")
+    net.load_state_dict(sub(G, f"step{1}/after/"))
+    net.eval()
+    x = G["euler/x_start"].to(DEV)
+    n = int(G["euler/n_steps"])
+    eager = euler_generate(net, x, n)
+    graphed = euler_generate(net, x, n, graph=True)
+    assert torch.equal(eager, graphed) and relerr(graphed, G["euler/x_end"]) < TOL
+    g0 = net._s2s_euler_graph
+    assert torch.equal(euler_generate(net, x, n, graph=True), eager) and net._s2s_euler_graph is g0      # cache hit
+    one = euler_generate(net, x[:1], 5, graph=True)                                                        # batch 1
+    assert torch.equal(one, euler_generate(net, x[:1], 5)) and net._s2s_euler_graph is not g0
+    a, sa = dopri5_generate(net, x[:1], return_stats=True)
+    b, sb = dopri5_generate(net, x[:1], return_stats=True, graph=True)
+    assert torch.equal(a, b) and sa == sb
+    mod = ConditionalFlowMatchingModule(net, solver=SolverConfig("euler"))
+    assert torch.equal(mod.generate(x, num_steps=n, graph=True), eager)
+    with torch.no_grad():
+        net.flow_decoder.outc.bias.add_(0.25)                      # new parameters: the capture must be rebuilt
+    moved = euler_generate(net, x, n, graph=True)
+    assert not torch.equal(moved, eager) and torch.equal(moved, euler_generate(net, x, n))
