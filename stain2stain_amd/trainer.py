@@ -167,8 +167,10 @@ class CFMTrainer:
         enc, dec = net.encoder, net.flow_decoder
         dt = enc.compute_dtype
         B = x0.shape[0]
+        x0, x1 = x0.float().contiguous(), x1.float().contiguous()       # NCHW fp32, the reference's boundary layout
         if t is None:
             t = torch.rand(B, device=x0.device, dtype=torch.float32)
+        t = t.float().contiguous()
         eps_noise = torch.randn_like(x0) if self.sigma != 0.0 else None
         xt, ut = ops.cfm_sample(x0, x1, t, self.sigma, eps_noise)
         ectx = engine.encoder_forward(enc._blocks, xt, dt, True)
