@@ -128,6 +128,7 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     losses = None
     for i in range(steps):
         sampled = i % every == 0
+        tr.overlap_wgrad = not sampled          # bracketed steps on one stream (see the note in the CFM loop)
         if sampled:
             ops.profile_start(None if args.breakdown else convs)
         losses = tr.step(*data[(warmup + i) % 4])
@@ -345,6 +346,9 @@ def main() -> None:
     for i in range(args.steps):
         x0, x1 = feed(args.warmup + i) if feed else pool[(args.warmup + i) % 4]
         sampled = i % every == 0
+        # the bracketed steps run on ONE stream, so that an event pair times its kernel alone; all other steps overlap
+        # the weight gradients with the bandwidth-bound backward passes on a side stream (engine.run_on_side)
+        trainer.overlap_wgrad = not sampled
         if sampled:
             ops.profile_start(only)
         loss = trainer.step(x0, x1, ts[args.warmup + i])
@@ -406,7 +410,10 @@ def main() -> None:
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/hbm_traffic_current.json)",
                          "launches_per_step": n_l // timed_steps, "launches_timed": n_l,
                          "avg_launch_ms": round(t_l * 1e3 / n_l, 4),
-                         "algorithmic_gflop_per_launch": round(f_l / n_l / 1e9, 3)},
+                         "algorithmic_gflop_per_launch": round(f_l / n_l / 1e9, 3),
+                         "note": "event-bracketed steps (1 in %d) run single-stream so a bracket times its kernel alone; "
+                                 "the other steps overlap the weight gradients with the HBM-bound backward passes on a "
+                                 "side stream (S2S_WGRAD_STREAM=0 disables it, e.g. for rocprofv3 kernel statistics)" % every},
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

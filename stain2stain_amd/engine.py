@@ -162,6 +162,41 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
     return None, act, pooled
 
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients on a side HIP stream
+# ------------------------------------------------------------------------------------------------
+# In the backward chain  BN-backward(L) -> { wgrad(L), dgrad(L) } -> BN-backward(L-1) -> ...  the weight gradient is
+# a leaf: nothing downstream of it but the gradient exchange and Adam.  It is MFMA-bound, while the BatchNorm /
+# up-sampling / pooling backward passes that follow on the critical path are HBM-bound, so the fused trainer issues the
+# weight-gradient launches on a second stream (fork on an event after the layer's BN backward, join before the gradient
+# bucket is exchanged / before Adam) and the two kinds of work share the chip.  ``side_stream`` is None on the
+# autograd-module path (everything on the current stream).
+side_stream: Optional[torch.cuda.Stream] = None
+
+
+def run_on_side(fn, keep=()) -> None:
+    """fn() on the side stream, ordered after everything enqueued on the current stream so far.  ``keep``: tensors the
+    side-stream work reads (the caching allocator must not hand their memory out again before it has run)."""
+    side = side_stream
+    if side is None:
+        fn()
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        fn()
+    for t in keep:
+        if t is not None:
+            t.record_stream(side)
+
+
+def join_side() -> None:
+    """The current stream waits for the side stream's work so far (before Adam reads the gradients)."""
+    if side_stream is not None:
+        torch.cuda.current_stream().wait_stream(side_stream)
+
+
 def _g(grads: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
     try:
         return grads[name]
@@ -179,9 +214,9 @@ def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool,
     draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
     dw = _g(grads, f"{p}.{i_conv}.weight")
     if stem:
-        ops.stem_wgrad(draw, lc.x0, dw, None, accumulate)
+        run_on_side(lambda: ops.stem_wgrad(draw, lc.x0, dw, None, accumulate), (draw,))
         return None
-    ops.conv3x3_wgrad(draw, lc.x0, lc.x1, dw, accumulate)
+    run_on_side(lambda: ops.conv3x3_wgrad(draw, lc.x0, lc.x1, dw, accumulate), (draw,))
     if not need_dx:
         return None
     dx, _ = ops.conv3x3(draw, None, cb.packed(draw.dtype)[1], None, cb.cin)

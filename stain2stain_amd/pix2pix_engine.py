@@ -23,13 +23,14 @@ backward-completion order (``trainer.FlatParams``), so gradient buckets are cont
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import engine, ops
 from .ddp import ALIGN, GradBucketer, all_reduce_mean_scalar, broadcast_from_rank0
 from .pix2pix import PatchGANDiscriminator, Pix2PixGenerator
 
@@ -139,8 +140,8 @@ def _conv_s2_fwd(l: _Layer, x: torch.Tensor, act: bool = False, slope: float = 0
 
 
 def _conv_s2_bwd(l: _Layer, g: torch.Tensor, saved: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True):
-    if want_w:
-        ops.convkxk_wgrad(g, saved, gw, 2, x_plain=(saved.shape[3] == l.conv_in))     # plain input vs space-to-depth image
+    if want_w:      # (a leaf of the backward chain: on the side stream when the trainer has one, engine.run_on_side)
+        engine.run_on_side(lambda: ops.convkxk_wgrad(g, saved, gw, 2, x_plain=(saved.shape[3] == l.conv_in)), (g,))
     if not need_dx:
         return None
     if g.dtype == torch.bfloat16 and l.conv_in % 64 == 0:
@@ -161,16 +162,16 @@ def _conv_t2_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, 
     # weight gradient with the roles exchanged (the result is nn.ConvTranspose2d's [Cin][Cout][4][4]); data gradient =
     # the stride-2 convolution of g with the forward operand
     if ops.fused_s2_ok(g.dtype, g.shape[3]):
-        ops.convkxk_wgrad(x, g, gw, 2, x_plain=True)
+        engine.run_on_side(lambda: ops.convkxk_wgrad(x, g, gw, 2, x_plain=True), (g,))
         return ops.conv4x4s2(g, l.wf, None, l.conv_in) if need_dx else None
     gs = ops.space_to_depth_pad1_t(g)
-    ops.convkxk_wgrad(x, gs, gw, 2)
+    engine.run_on_side(lambda: ops.convkxk_wgrad(x, gs, gw, 2), (gs,))
     return ops.convkxk(gs, l.wf, None, l.conv_in, 2, 0) if need_dx else None
 
 
 def _conv_s1_bwd(l: _Layer, g: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, want_w: bool = True) -> torch.Tensor:
     if want_w:
-        ops.convkxk_wgrad(g, x, gw, 4)
+        engine.run_on_side(lambda: ops.convkxk_wgrad(g, x, gw, 4), (g,))
     return ops.convkxk(g, l.wd, None, l.conv_in, 4, 2)
 
 
@@ -225,7 +226,24 @@ class Pix2PixTrainer:
         self.packG = _Packer(self.g_down + self.g_up, self.dtype)
         self.packD = _Packer(self.d_layers, self.dtype)
         self.in_channels, self.out_channels = G.in_channels, G.out_channels
+        # weight gradients overlap the bandwidth-bound backward passes on a second HIP stream (engine.run_on_side);
+        # S2S_WGRAD_STREAM=0 keeps everything on one stream, overlap_wgrad = False does so for a single step
+        self._side = torch.cuda.Stream(device=dev) if os.environ.get("S2S_WGRAD_STREAM", "1") != "0" else None
+        self.overlap_wgrad = True
         self.last: Dict[str, torch.Tensor] = {}
+
+    def _mark(self, fp: FlatParams, group: int) -> None:
+        """Group ``group`` of ``fp`` has its gradients enqueued (weight gradient on the side stream, which was forked
+        after the layer's other gradients): exchange the buckets it closes, ordered behind the side stream."""
+        if engine.side_stream is not None and fp.bucketer.enabled:
+            with torch.cuda.stream(engine.side_stream):
+                fp.bucketer.mark_ready(group)
+        else:
+            fp.bucketer.mark_ready(group)
+
+    def _join(self) -> None:
+        engine.join_side()
+        engine.side_stream = None
 
     # ------------------------------------------------------------------------------------------------------------
     # generator
@@ -294,7 +312,7 @@ class Pix2PixTrainer:
                 g = dx
             else:
                 dcat[j] = dx
-            bk.mark_ready(grp); grp += 1
+            self._mark(self.pG, grp); grp += 1
         for i in range(n - 1, -1, -1):
             l = self.g_down[i]
             skip_g = dcat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
@@ -305,7 +323,7 @@ class Pix2PixTrainer:
             else:
                 g = ops.instnorm_lrelu_bwd2(g, skip_g, ctx.raw[i], ctx.stats[i], LRELU)
             g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0))
-            bk.mark_ready(grp); grp += 1
+            self._mark(self.pG, grp); grp += 1
 
     # ------------------------------------------------------------------------------------------------------------
     # discriminator
@@ -337,23 +355,23 @@ class Pix2PixTrainer:
             ops.channel_sum_into(dz, gr["c5.bias"])
         g = _conv_s1_bwd(c5, dz, a4, gr["c5.weight"], want_w)
         if want_w:
-            bk.mark_ready(0)
+            self._mark(self.pD, 0)
         g = ops.instnorm_lrelu_bwd2(g, None, r4, s4, LRELU)
         g = _conv_s1_bwd(c4, g, a3, gr["c4.weight"], want_w)
         if want_w:
-            bk.mark_ready(1)
+            self._mark(self.pD, 1)
         g = ops.instnorm_lrelu_bwd2(g, None, r3, s3, LRELU)
         g = _conv_s2_bwd(c3, g, xs3, gr["c3.weight"], True, want_w)
         if want_w:
-            bk.mark_ready(2)
+            self._mark(self.pD, 2)
         g = ops.instnorm_lrelu_bwd2(g, None, r2, s2, LRELU)
         g = _conv_s2_bwd(c2, g, xs2, gr["c2.weight"], True, want_w)
         if want_w:
-            bk.mark_ready(3)
+            self._mark(self.pD, 3)
         g = ops.p2p_act_bwd(g, None, a1, LRELU, gr["c1.bias"] if want_w else None)
         g = _conv_s2_bwd(c1, g, xs1, gr["c1.weight"], need_input_grad, want_w)
         if want_w:
-            bk.mark_ready(4)
+            self._mark(self.pD, 4)
         return g
 
     # ------------------------------------------------------------------------------------------------------------
@@ -379,7 +397,9 @@ class Pix2PixTrainer:
         z, saved = self.d_forward(d_in)
         npatch = z.shape[1] * z.shape[2]
         _, dz = ops.p2p_bce_logits(z, B, 0.5 / (B * npatch), 0.5 / (B * npatch), out=losses[0:2])
+        engine.side_stream = self._side if self.overlap_wgrad else None
         self.d_backward(saved, dz, want_w=True, need_input_grad=False)
+        self._join()
         if update:
             self.pD.adam(self.lr, self.betas, self.eps, self.wd)
             self.packD.repack()
@@ -391,7 +411,9 @@ class Pix2PixTrainer:
         _, dzg = ops.p2p_bce_logits(zg, B, 1.0 / (B * npatch), 0.0, out=losses[2:4])
         gd = self.d_backward(saved_g, dzg, want_w=False, need_input_grad=True)
         dh = ops.p2p_tanh_l1_bwd(gctx.h, tgt, gd, self.lambda_l1 / (B * C * H * W))
+        engine.side_stream = self._side if self.overlap_wgrad else None
         self.g_backward(gctx, dh)
+        self._join()
         if update:
             self.pG.adam(self.lr, self.betas, self.eps, self.wd)
             self.packG.repack()

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -144,6 +146,10 @@ class CFMTrainer:
             wf, wd = cb.ensure_buffers(self._dtype)
             rows.append([cb.conv.weight.data_ptr(), wf.data_ptr(), wd.data_ptr(), cb.cout, cb.cin, start])
             start += ((cb.cout + 31) // 32) * ((cb.cin + 31) // 32)
+        # weight gradients overlap the bandwidth-bound backward passes on a second HIP stream (engine.run_on_side);
+        # S2S_WGRAD_STREAM=0 keeps everything on one stream
+        self._side = torch.cuda.Stream(device=dev) if os.environ.get("S2S_WGRAD_STREAM", "1") != "0" else None
+        self.overlap_wgrad = True       # bench.py clears it on the steps whose kernels it brackets with HIP events
         self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._pack_total = start
         self._repack()
@@ -185,19 +191,33 @@ class CFMTrainer:
         dctx.v = v
         self.bucketer.start_step()
         self._group = 0
-        dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
-                                                   on_group_done=self._group_done)
-        L = len(feats) - 1
-        dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
-        engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
+        engine.side_stream = self._side if self.overlap_wgrad else None
+        try:
+            dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
+                                                       on_group_done=self._group_done)
+            L = len(feats) - 1
+            dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
+            engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
+        finally:
+            engine.side_stream = None
+        if self._side is not None:          # whatever reads the gradients next (Adam, a test) is on the compute stream
+            torch.cuda.current_stream().wait_stream(self._side)
         return loss, dctx.v
 
     def _group_done(self) -> None:
-        """The next parameter group (layer, in _param_groups order) has its gradients enqueued."""
-        self.bucketer.mark_ready(self._group)
+        """The next parameter group (layer, in _param_groups order) has its gradients enqueued: the layer's BatchNorm
+        gradients on the compute stream, its weight gradient on the side stream, which was forked after them -- so the
+        bucket's collective is ordered behind the side stream."""
+        if self._side is not None and self.overlap_wgrad and self.bucketer.enabled:
+            with torch.cuda.stream(self._side):
+                self.bucketer.mark_ready(self._group)
+        else:
+            self.bucketer.mark_ready(self._group)
         self._group += 1
 
     def optimizer_step(self) -> None:
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)     # the weight gradients
         self.bucketer.wait_all()
         self.step_count += 1
         for lo, hi in self.bucketer.shards():          # everything, or this rank's slices in sharded mode
