@@ -11,6 +11,10 @@ os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
 shutil.copy(f"{src}/stats/k_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+for a, b in (("p2p_stats/k_kernel_stats.csv", "pix2pix_kernel_stats.csv"), ("p2p_bench_under_rocprof.json", "pix2pix_bench_under_rocprof.json"),
+             ("stats_overlap/k_kernel_stats.csv", "kernel_stats_two_streams.csv")):
+    if os.path.exists(f"{src}/{a}"):
+        shutil.copy(f"{src}/{a}", f"profiles/{tag}_{b}")
 
 
 def per_kernel(path, counter):
@@ -58,3 +62,30 @@ for label, needle in groups.items():
                         "avg_launch_us": round(tot / n / 1e3, 2),
                         "hbm_gb_per_s_from_counters": round(out[label]["hbm_bytes_per_launch_corrected"] / (tot / n), 1)}
 json.dump(rates, open(f"profiles/{tag}_hbm_rates.json", "w"), indent=1)
+
+# ---- the pix2pix G + D step (row a13): same counters, its own kernels ----
+if os.path.exists(f"{src}/p2p_pmc_fetch/f_counter_collection.csv"):
+    fetch = per_kernel(f"{src}/p2p_pmc_fetch/f_counter_collection.csv", "FETCH_SIZE")
+    write = per_kernel(f"{src}/p2p_pmc_write/w_counter_collection.csv", "WRITE_SIZE")
+    stats = list(csv.DictReader(open(f"{src}/p2p_stats/k_kernel_stats.csv")))
+    groups = {"convkxk (4x4 forward / data gradient / transposed)": "convkxk_dma16_kernel",
+              "conv2x2_wgrad (4x4 stride-2 weight gradient)": "conv2x2_wgrad_dma_kernel",
+              "convkxk_wgrad_rows (4x4 stride-1 weight gradient)": "convkxk_wgrad_rows_kernel",
+              "wgrad_fold4x4": "wgrad_fold4x4_kernel", "instnorm reduce": "in_reduce_kernel",
+              "instnorm apply": "in_lrelu_apply_kernel", "instnorm bwd apply": "in_lrelu_bwd_apply_kernel",
+              "adam": "adam_kernel", "pack4x4": "pack4x4_batched_kernel", "act_bwd": "p2p_act_bwd_kernel"}
+    out = {}
+    for label, needle in groups.items():
+        f = [v for k, vs in fetch.items() if needle in k for v in vs]
+        w = [v for k, vs in write.items() if needle in k for v in vs]
+        tot = sum(float(r["TotalDurationNs"]) for r in stats if needle in r["Name"])
+        n = sum(int(r["Calls"]) for r in stats if needle in r["Name"])
+        if not f or not w or not n:
+            continue
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        out[label] = {"launches_sampled": len(f), "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024),
+                      "avg_launch_us": round(tot / n / 1e3, 2),
+                      "hbm_gb_per_s_from_counters": round((2 * fk + wk) * 1024 / (tot / n), 1)}
+    json.dump(out, open(f"profiles/{tag}_pix2pix_hbm_rates.json", "w"), indent=1)
+    for k, v in out.items():
+        print(f"pix2pix {k:52s} {v['hbm_bytes_per_launch_corrected']/1e6:9.1f} MB/launch {v['hbm_gb_per_s_from_counters']:8.1f} GB/s")

@@ -65,6 +65,27 @@ def _L():
 
 
 # ------------------------------------------------------------------------------------------------
+# persistent scratch for the split-K slabs
+# ------------------------------------------------------------------------------------------------
+# The weight-gradient kernels write tens of MB of fp32 partial slabs per launch.  Taking them from torch's caching
+# allocator ties them to the stream that happens to be current (the allocator pools per stream): a step that runs its
+# weight gradients on another stream than the previous one finds no cached block, falls through to hipMalloc and stalls
+# the queue for ~0.2 ms per launch.  One grow-only buffer per (device, tag) instead; every user of a tag issues its
+# launches on one stream at a time (the weight gradients of a step are serialised on the side stream, and joined before
+# the next step), so consecutive launches may share it.
+_WORKSPACE = {}
+
+
+def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _WORKSPACE.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty((max(numel, 1 << 20),), dtype=torch.float32, device=device)
+        _WORKSPACE[key] = buf
+    return buf[:numel]
+
+
+# ------------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
 # ------------------------------------------------------------------------------------------------
 _PROFILE: Optional[list] = None
@@ -167,7 +188,7 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
     if tuple(grad_oihw.shape) != (cout, c0 + c1, 3, 3):
         raise RuntimeError("stain2stain_amd: conv3x3_wgrad gradient buffer has the wrong shape")
     s = _L().s2s_conv3x3_wgrad_splits(dt, B, H, W, c0 + c1, cout)
-    part = torch.empty((s, 9, cout, c0 + c1), dtype=torch.float32, device=dy.device)
+    part = _workspace(dy.device, s * 9 * cout * (c0 + c1), "wgrad")
     rc = _L().s2s_conv3x3_wgrad_nhwc(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
                                      int(accumulate), B, H, W, _stream())
     _native.check(rc, "conv3x3_wgrad")
@@ -824,7 +845,7 @@ def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int
     px, ldx = _nhwc(x)
     s = _L().s2s_convkxk_wgrad_splits(_dt(dy), B, H, W, cin, cout, ks)
     _native.check(min(s, 0), "convkxk_wgrad_splits")
-    part = torch.empty((s, ks * ks, cout, cin), dtype=torch.float32, device=dy.device)
+    part = _workspace(dy.device, s * ks * ks * cout * cin, "wgrad")
     rc = _L().s2s_convkxk_wgrad_nhwc(_dt(dy), pdy, lddy, cout, px, ldx, cin, _f32(part), grad.data_ptr(), 1,
                                      int(accumulate), B, H, W, ks, int(x_plain), _stream())
     _native.check(rc, "convkxk_wgrad")
