@@ -58,6 +58,7 @@ struct Conv3x3Args {
   float* kpart;
   int ksplit;
   int lgc;        // convkxk MODE 1: log2 of the real input channel count (a.c0 = 4 << lgc virtual channels)
+  int lgh, lgw;   // convflat_dma16_kernel: log2 of the map size the flattened pixel index is decoded with
   int bias_mod;   // bias index = channel % bias_mod (= Cout normally; Cout / 4 for the transposed 4x4 layers, whose four
                   // sub-pixel channel groups share one bias vector)
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
@@ -1175,6 +1176,192 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
+// =========================================================================================================
+// FLAT form of MODE 1 / MODE 2 for the inner U-Net levels (maps of at most 8x8): the output tile is 128 consecutive
+// pixels of the FLATTENED batch (pixel p = (n, i, j)), not a 2-D window of one image.  A 4x4 map fills 16 of the 128
+// pixels of an 8x16 window, and every image's workgroups then stream the layer's whole 8-17 MB weight operand from L2
+// (16 images: 130-270 MB per launch, 20-70 us for 0.1-17 GFLOP); here the batch shares tiles and the operand is
+// streamed once per 128 pixels.  The halo image is replaced by an im2col image in LDS -- one [128 pixels][32 ch]
+// plane per tap, filled by per-lane DMA addresses -- so the tap is again a constant LDS offset.  Always split-K: the
+// fp32 partial tile goes to kpart[z][output pixel][C] and convk_splitk_reduce_kernel finishes (bias, activation).
+//   MODE 1: conv 4x4 s2 from the plain input [B][2h][2w][Cin] (a.c0 = 4 Cin virtual channels), a.H / a.W = h, w output
+//   MODE 2: transposed conv by phase, a.H / a.W = h, w input, plain output [B][2h][2w][C]
+// h, w powers of two (a.lgh, a.lgw).
+// =========================================================================================================
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
+  using T = bf16_t;
+  constexpr int TAPS = 4, NS = 4, WM = 2, WN = 2, BM = 128;
+  constexpr int HG = TAPS * BM / 16 / 4;               // DMA instructions per wave and chunk for the im2col planes (8)
+  constexpr int PLANE = BM * 64, A_BYTES = TAPS * PLANE;
+  constexpr int BG = BN / 64, B_BYTES = BN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  static_assert(MODE == 1 || MODE == 2, "flat forms of the layout-free kernels");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;
+  char* const ldsB = smem + 2 * A_BYTES;
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const char* __restrict__ wp = static_cast<const char*>(a.w);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int cl = lane & 15, kp = lane >> 4;
+  const int p0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int h = 1 << a.lgh, w = 1 << a.lgw;
+  const int npix = a.B << (a.lgh + a.lgw);
+  const int phase = MODE == 2 ? (int)blockIdx.z / a.ksplit : 0, zk = (int)blockIdx.z - phase * a.ksplit;
+  const int pad_y = MODE == 2 ? (phase >> 1) : 0, pad_x = MODE == 2 ? (phase & 1) : 0;
+  const int c_lo = (int)(((long)zk * a.nchunk) / a.ksplit), c_hi = (int)(((long)(zk + 1) * a.nchunk) / a.ksplit);
+  const int wrows = MODE == 2 ? 4 * a.Cout : a.Cout, wrow0 = (MODE == 2 ? phase * a.Cout : 0) + n0;
+
+  const int drow = lane >> 2, dslot = lane & 3;
+  int apix[HG], apc[HG];
+#pragma unroll
+  for (int j = 0; j < HG; ++j) {
+    const int row = (wave + 4 * j) * 16 + drow;               // LDS row: plane = tap, row inside the plane = tile pixel
+    const int tap = row >> 7, m = row & (BM - 1);
+    const int p = p0 + m;
+    const int n = p >> (a.lgh + a.lgw), iy = (p >> a.lgw) & (h - 1), ix = p & (w - 1);
+    const int yy = iy + (tap >> 1) - pad_y, xx = ix + (tap & 1) - pad_x;      // MODE 1: cell; MODE 2: input pixel
+    if (MODE == 1) apix[j] = p < npix ? ((n << 8) | (yy << 4) | xx) : -1;
+    else apix[j] = (p < npix && yy >= 0 && yy < h && xx >= 0 && xx < w) ? (n * h + yy) * w + xx : -1;
+    apc[j] = (dslot ^ ((-(m >> 2)) & 3)) * 8;
+  }
+  const char* wptr[BG];
+  int wstep[BG];
+#pragma unroll
+  for (int j = 0; j < BG; ++j) {
+    const int n = (wave + 4 * j) * 16 + drow;
+    const bool ok = n0 + n < a.Cout;
+    wptr[j] = ok ? wp + (long)c_lo * TAPS * wrows * 64 + ((long)(wrow0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
+    wstep[j] = ok ? wrows * 64 : 0;
+  }
+  auto dma_planes = [&](int c) {
+    char* dst = ldsA + (c & 1) * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      const int ch = c * 32 + apc[j];
+      const void* g = g_zero_page;
+      if (MODE == 1) {
+        if (apix[j] >= 0 && ch < a.c0) {
+          const int rs = ch >> a.lgc, cc = ch & ((1 << a.lgc) - 1);
+          const int py = 2 * ((apix[j] >> 4) & 15) + (rs >> 1) - 1, px = 2 * (apix[j] & 15) + (rs & 1) - 1;
+          if ((unsigned)py < (unsigned)(2 * h) && (unsigned)px < (unsigned)(2 * w))
+            g = x0 + ((long)((apix[j] >> 8) * 2 * h + py) * (2 * w) + px) * a.ld0 + cc;
+        }
+      } else if (apix[j] >= 0 && ch < a.c0) {
+        g = x0 + (long)apix[j] * a.ld0 + ch;
+      }
+      dma16(g, dst + j * 4096);
+    }
+  };
+  auto dma_w = [&](int slot) {
+    char* dst = ldsB + slot * B_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      dma16(wptr[j], dst + j * 4096);
+      wptr[j] += wstep[j];
+    }
+  };
+  int aofs[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 16 + cl;
+    aofs[mi] = m * 64 + ((kp ^ ((-(m >> 2)) & 3)) << 4);
+  }
+  const int nrow = wn * WTN + cl;
+  const int bofs = nrow * 64 + ((kp ^ ((-(nrow >> 2)) & 3)) << 4);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
+
+  auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
+    constexpr int tap = decltype(tapc)::value;
+    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(Ab + tap * PLANE + aofs[mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+  };
+  dma_planes(c_lo);
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int c = c_lo;
+  for (; c + 1 < c_hi; ++c) {
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * TAPS;
+    static_for<TAPS>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap == 0) dma_planes(c + 1);
+      dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  {
+    const char* Ab = ldsA + (c & 1) * A_BYTES;
+    const int it0 = c * TAPS;
+    static_for<TAPS>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap + NS - 1 < TAPS) dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + NS - 1 < TAPS) wait_vm<(NS - 2) * BG>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  // fp32 partial tile -> kpart[zk][output pixel][C]
+  const long out_pix = MODE == 2 ? 4L * npix : (long)npix;
+  float* const kpz = a.kpart + (long)zk * out_pix * a.Cout;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = p0 + wm * WTM + mi * 16 + cl;
+    if (p < npix) {
+      long op = p;
+      if (MODE == 2) {
+        const int n = p >> (a.lgh + a.lgw), iy = (p >> a.lgw) & (h - 1), ix = p & (w - 1);
+        op = ((long)n * 2 * h + 2 * iy + 1 - pad_y) * (2 * w) + 2 * ix + 1 - pad_x;
+      }
+      float* const row = kpz + op * a.Cout;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * WTN + ni * 16 + 4 * kp;
+        if (n < a.Cout) *reinterpret_cast<f32x4*>(row + n) = acc[mi][ni];
+      }
+    }
+  }
+}
+
+template <int BN, int MODE>
+int launch_convflat(Conv3x3Args& a, hipStream_t s) {
+  constexpr int lds = 2 * 4 * 128 * 64 + 4 * BN * 64;
+  auto kern = convflat_dma16_kernel<BN, MODE>;
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
+  const int npix = a.B << (a.lgh + a.lgw);
+  dim3 grid(cdiv(npix, 128), cdiv(a.Cout, BN), a.ksplit * (MODE == 2 ? 4 : 1));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 // out[p][n] = act(sum_z kpart[z][p][n] + bias[n % bias_mod]) for the split-K launches; 8 channels per thread
 template <typename T>
 __global__ __launch_bounds__(256) void convk_splitk_reduce_kernel(Conv3x3Args a, long npix) {
@@ -1509,7 +1696,7 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
   Conv3x3Args a;
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0; a.lgh = a.lgw = 0;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
@@ -1661,6 +1848,19 @@ static int s2_tile(int B, int H, int W, int C, int mult, long* blocks) {
   return best;
 }
 
+// The flat form applies to power-of-two maps of at most 8x8 with at least two chunks to split; it always runs split-K
+// (>= 2), ~256 workgroups.
+static bool s2_flat_ok(int H, int W, int nchunk) {
+  return H <= 8 && W <= 8 && (H & (H - 1)) == 0 && (W & (W - 1)) == 0 && nchunk >= 2;
+}
+static int s2_flat_ksplit(int B, int H, int W, int C, int phases, int nchunk) {
+  const long base = (long)phases * cdiv(B * H * W, 128) * cdiv(C, C > 64 ? 128 : 64);
+  long sp = (256 + base - 1) / base;
+  if (sp > nchunk) sp = nchunk;
+  if (sp > 32) sp = 32;
+  return sp < 2 ? 2 : (int)sp;
+}
+
 static int s2_ksplit(long base, int nchunk) {
   if (base >= 192 || nchunk < 8) return 1;
   long sp = (512 + base - 1) / base;
@@ -1671,6 +1871,7 @@ static int s2_ksplit(long base, int nchunk) {
 
 extern "C" int s2s_conv4x4s2_ksplit(int B, int H, int W, int Cout, int Cin) {
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
+  if (s2_flat_ok(H, W, cdiv(4 * Cin, 32))) return s2_flat_ksplit(B, H, W, Cout, 1, cdiv(4 * Cin, 32));
   long base;
   s2_tile(B, H, W, Cout, 1, &base);
   return s2_ksplit(base, cdiv(4 * Cin, 32));
@@ -1696,6 +1897,10 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
+  if (a.kpart && s2_flat_ok(H, W, a.nchunk)) {
+    a.lgh = __builtin_ctz((unsigned)H); a.lgw = __builtin_ctz((unsigned)W);
+    rc = Cout > 64 ? launch_convflat<128, 1>(a, s) : launch_convflat<64, 1>(a, s);
+  } else
   switch (s2_tile(B, H, W, Cout, 1, nullptr)) {
     case 0: rc = launch_convkxk<8, 32, 128, 2, 2, 2, 0, 1>(a, s); break;
     case 1: rc = launch_convkxk<8, 32, 64, 4, 1, 2, 0, 1>(a, s); break;
@@ -1715,6 +1920,7 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
 
 extern "C" int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin) {
   if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || Cin <= 0) return S2S_ERR_SHAPE;
+  if (s2_flat_ok(h, w, cdiv(Cin, 32))) return s2_flat_ksplit(B, h, w, C, 4, cdiv(Cin, 32));
   long base;
   s2_tile(B, h, w, C, 4, &base);
   return s2_ksplit(base, cdiv(Cin, 32));
@@ -1738,6 +1944,10 @@ extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, c
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
+  if (a.kpart && s2_flat_ok(h, w, a.nchunk)) {
+    a.lgh = __builtin_ctz((unsigned)h); a.lgw = __builtin_ctz((unsigned)w);
+    rc = C > 64 ? launch_convflat<128, 2>(a, s) : launch_convflat<64, 2>(a, s);
+  } else
   switch (s2_tile(B, h, w, C, 4, nullptr)) {
     case 0: rc = launch_convkxk<8, 32, 128, 2, 2, 2, 1, 2>(a, s); break;
     case 1: rc = launch_convkxk<8, 32, 64, 4, 1, 2, 1, 2>(a, s); break;

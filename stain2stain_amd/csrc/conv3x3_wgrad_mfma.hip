@@ -30,6 +30,7 @@ struct WgradArgs {
   int lddy, Cout, ld0, c0, ld1, c1;
   int B, H, W, tilesY, tilesX, ntiles, S;
   int lgc;   // conv2x2_wgrad_dma_kernel<.., S2D = true>: log2 of the real channel count of the plain X tensor
+  int lgh, lgw;   // conv2x2_wgrad_flat_kernel: log2 of the (output) map size
 };
 
 namespace {
@@ -634,6 +635,101 @@ __global__ __launch_bounds__(256, 2) void conv2x2_wgrad_dma_kernel(WgradArgs a) 
   }
 }
 
+// FLAT form of the S2D kernel above for the inner U-Net levels (maps of at most 8x8; see convflat_dma16_kernel): a
+// pixel tile is 128 consecutive pixels of the FLATTENED batch, so sixteen 1x1 ... 4x4 images share one or two tiles
+// instead of each occupying an eighth-full 8x16 window of its own (16 loop iterations of mostly zeros).  The halo
+// image is replaced by one [128 pixels][32 ch] plane per tap, filled by per-lane DMA addresses.  Single-buffered: a
+// workgroup sees one to eight tiles.  Same part[split][4][Cout][cin] slabs.
+__global__ __launch_bounds__(256, 1) void conv2x2_wgrad_flat_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = 4, NPX = 128;
+  constexpr int DY_BYTES = 2 * NPX * 64, PLANE = NPX * 64, X_BYTES = 2 * NT * PLANE;
+  constexpr int DYG = 2 * NPX / 16 / 4;                  // 4
+  constexpr int XG = 2 * NT * NPX / 16 / 4;              // 16
+  constexpr int KSTEPS = NPX / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int cin = a.c0;
+  const int h = 1 << a.lgh, w = 1 << a.lgw;
+  const int npix = a.B << (a.lgh + a.lgw);
+  const int drow = lane >> 2, dslot = lane & 3;
+  const int zsplit = (int)blockIdx.z;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p4 * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  auto dma_tile = [&](int tile) {
+    const int p0 = tile * NPX;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int j = 0; j < DYG; ++j) {
+      const int grp = wave + 4 * j;
+      const int half = grp / (NPX / 16), m = (grp % (NPX / 16)) * 16 + drow;
+      const int co = co0 + half * 32 + dslot * 8, p = p0 + m;
+      const void* src = g_wgrad_zero_page;
+      if (p < npix && co < a.Cout) src = dy + (long)p * a.lddy + co;
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + grp * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < XG; ++j) {
+      const int grp = wave + 4 * j;                          // 64 groups: [half][tap][8 groups of 16 pixels]
+      const int half = grp >> 5, tap = (grp >> 3) & 3, m = (grp & 7) * 16 + drow;
+      const int ci = ci0 + half * 32 + dslot * 8, p = p0 + m;
+      const void* src = g_wgrad_zero_page;
+      if (p < npix && ci < cin) {
+        const int n = p >> (a.lgh + a.lgw), iy = (p >> a.lgw) & (h - 1), ix = p & (w - 1);
+        const int rs = ci >> a.lgc, cc = ci & ((1 << a.lgc) - 1);
+        const int py = 2 * (iy + (tap >> 1)) + (rs >> 1) - 1, px = 2 * (ix + (tap & 1)) + (rs & 1) - 1;
+        if ((unsigned)py < (unsigned)(2 * h) && (unsigned)px < (unsigned)(2 * w))
+          src = x0 + ((long)(n * 2 * h + py) * (2 * w) + px) * a.ld0 + cc;
+      }
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + grp * 1024));
+    }
+  };
+
+  for (int tile = zsplit; tile < a.ntiles; tile += a.S) {
+    dma_tile(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* const Ahi = smem + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + DY_BYTES + wci * (NT * PLANE) + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 bfr = tr_frag(Bhi + t * PLANE + m0 * 64, 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // every wave has read this tile before the next one lands
+  }
+  const int r = lane & 31, hh = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+      if (co < a.Cout && ci < cin) a.part[(((long)zsplit * NT + t) * a.Cout + co) * cin + ci] = acc[t][j];
+    }
+  }
+}
+
 // KS x KS taps, stride 1 (row a13: the PatchGAN's 4x4 stride-1 pad-1 layers, KS = 4, PAD = 1):
 //   dW[kh*KS+kw][co][ci] = sum_{n,i,j} dY[n][i][j][co] * X[n][i+kh-PAD][j+kw-PAD][ci],   X is (H+KS-1-2PAD) wide.
 // Sixteen 32x32 accumulators do not fit a wave, so the kernel rows go to KS workgroups (blockIdx.z = split*KS + kh,
@@ -999,7 +1095,7 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   WgradArgs a;
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
-  a.B = B; a.H = H; a.W = W; a.lgc = 0;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
   a.S = s2s_conv3x3_wgrad_splits(dtype, B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
@@ -1040,7 +1136,7 @@ extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W; a.lgc = 0;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
   a.S = conv2x2_wgrad_splits(B, H, W, cin, Cout);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1086,7 +1182,7 @@ extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W; a.lgc = 0;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
   a.S = s2s_conv4x4s1_wgrad_splits(B, H, W, cin, Cout);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1157,7 +1253,7 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   WgradArgs a;
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
-  a.B = B; a.H = H; a.W = W; a.lgc = 0;
+  a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
   a.S = s2s_convkxk_wgrad_splits(dtype, B, H, W, cin, Cout, ks);
   a.tilesY = cdiv(H, 8); a.tilesX = cdiv(W, 16);
   a.ntiles = B * a.tilesY * a.tilesX;
@@ -1169,7 +1265,21 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   } else if (ks == 2) {
     constexpr int XROWS = ((TH + 1) * (TW + 1) + 31) / 32 * 32;
     constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
-    if (x_plain) {
+    if (x_plain && H <= 8 && W <= 8 && (H & (H - 1)) == 0 && (W & (W - 1)) == 0) {
+      // inner U-Net levels: tiles of the flattened batch (fewer splits than the slab buffer was sized for)
+      a.lgc = __builtin_ctz((unsigned)(cin / 4));
+      a.lgh = __builtin_ctz((unsigned)H); a.lgw = __builtin_ctz((unsigned)W);
+      a.ntiles = cdiv(B * H * W, 128);
+      const int mn = cdiv(cin, 64) * cdiv(Cout, 64);
+      int sp = 512 / mn;
+      if (sp > a.ntiles) sp = a.ntiles;
+      if (sp > a.S) sp = a.S;
+      a.S = sp < 1 ? 1 : sp;
+      constexpr int lds_flat = 2 * 128 * 64 + 2 * 4 * 128 * 64;
+      static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+      if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(conv2x2_wgrad_flat_kernel), lds_flat, &attr_devs)) return rc2;
+      hipLaunchKernelGGL(conv2x2_wgrad_flat_kernel, dim3(cdiv(cin, 64), cdiv(Cout, 64), a.S), dim3(256), lds_flat, s, a);
+    } else if (x_plain) {
       a.lgc = __builtin_ctz((unsigned)(cin / 4));
       auto kern = conv2x2_wgrad_dma_kernel<TH, TW, true>;
       static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
