@@ -367,3 +367,26 @@ def test_headline_networks_fp32_forward_and_discriminator():
     print(f"headline fp32: G output {relerr(fake, fake_o):.2e}, D logits {relerr(z[..., 0].cpu(), z_o[:, 0]):.2e}")
     assert fake.shape == (2, 3, 256, 256) and z.shape == (2, 30, 30, 8)
     assert relerr(fake, fake_o) < TOL and relerr(z[..., 0].cpu(), z_o[:, 0]) < TOL
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_rectangular_non_power_of_two_tiles(prec, tol):
+    """96 x 160 tiles with five levels: maps of 48x80 ... 3x5 -- wide and narrow tile forms, ragged tile edges, and inner
+    maps that are NOT powers of two (so the flat-pixel kernels must stand aside); generator output and both losses against
+    the oracle, in both precisions, plus a training step that stays finite."""
+    from stain2stain_amd import Pix2PixTrainer
+    G, D, Go, Do = _build(16, 16, 5, 5, bf16_weights=(prec == "bf16"))
+    g = torch.Generator().manual_seed(55)
+    rb = (lambda t: t.to(torch.bfloat16).float()) if prec == "bf16" else (lambda t: t)
+    src, tgt = rb(torch.rand(3, 3, 96, 160, generator=g) * 2 - 1), rb(torch.rand(3, 3, 96, 160, generator=g) * 2 - 1)
+    fake_o, ld_o, lg_o, _ = _oracle_eval(Go, Do, src, tgt)
+    tr = Pix2PixTrainer(G, D, precision=prec)
+    losses, fake = tr.losses_and_grads(src.to(DEV), tgt.to(DEV), update=False, want_fake=True)
+    ld, lg = tr.loss_values(losses)
+    err = relerr(fake, fake_o) if prec == "fp32" else _l2(fake, fake_o)
+    print(f"{prec} 96x160: fake {err:.2e}, loss_D {ld:.5f} vs {ld_o:.5f}, loss_G {lg:.4f} vs {lg_o:.4f}")
+    assert err < tol and abs(ld - ld_o) < max(tol, 5e-3) * abs(ld_o) and abs(lg - lg_o) < max(tol, 5e-3) * abs(lg_o)
+    v = tr.loss_values(tr.step(src.to(DEV), tgt.to(DEV)))
+    assert all(x == x and abs(x) < 1e4 for x in v)
+    with pytest.raises(ValueError, match="multiple of"):
+        tr.g_forward(torch.rand(1, 3, 100, 160, device=DEV))
