@@ -1188,10 +1188,13 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
 //   MODE 2: transposed conv by phase, a.H / a.W = h, w input, plain output [B][2h][2w][C]
 // h, w powers of two (a.lgh, a.lgw).
 // =========================================================================================================
-template <int BN, int MODE>
+// These launches are latency-bound, not MFMA-bound (a tap is ~0.1 us of matrix work, its weight slab an HBM round trip),
+// so the weight ring is NS = 8 slots deep -- seven taps of prefetch -- and the loop is uniform: slabs and planes past the
+// workgroup's range are fetched from the zero page, which keeps every s_waitcnt count a compile-time constant.
+template <int BN, int MODE, int NS>
 __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
   using T = bf16_t;
-  constexpr int TAPS = 4, NS = 4, WM = 2, WN = 2, BM = 128;
+  constexpr int TAPS = 4, WM = 2, WN = 2, BM = 128;
   constexpr int HG = TAPS * BM / 16 / 4;               // DMA instructions per wave and chunk for the im2col planes (8)
   constexpr int PLANE = BM * 64, A_BYTES = TAPS * PLANE;
   constexpr int BG = BN / 64, B_BYTES = BN * 64;
@@ -1241,11 +1244,13 @@ __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
   }
   auto dma_planes = [&](int c) {
     char* dst = ldsA + (c & 1) * A_BYTES + wave * 1024;
+    const bool live = c < c_hi;
 #pragma unroll
     for (int j = 0; j < HG; ++j) {
       const int ch = c * 32 + apc[j];
       const void* g = g_zero_page;
-      if (MODE == 1) {
+      if (!live) {
+      } else if (MODE == 1) {
         if (apix[j] >= 0 && ch < a.c0) {
           const int rs = ch >> a.lgc, cc = ch & ((1 << a.lgc) - 1);
           const int py = 2 * ((apix[j] >> 4) & 15) + (rs >> 1) - 1, px = 2 * (apix[j] & 15) + (rs & 1) - 1;
@@ -1258,11 +1263,12 @@ __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
       dma16(g, dst + j * 4096);
     }
   };
-  auto dma_w = [&](int slot) {
+  const int total = (c_hi - c_lo) * TAPS;              // weight slabs of this workgroup
+  auto dma_w = [&](int slot, int it) {
     char* dst = ldsB + slot * B_BYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
-      dma16(wptr[j], dst + j * 4096);
+      dma16(it < total ? wptr[j] : g_zero_page, dst + j * 4096);
       wptr[j] += wstep[j];
     }
   };
@@ -1297,36 +1303,30 @@ __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   };
   dma_planes(c_lo);
-  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value, decltype(k)::value); });
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  int c = c_lo;
-  for (; c + 1 < c_hi; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
-    const int it0 = c * TAPS;
+    const int it0 = (c - c_lo) * TAPS;
     static_for<TAPS>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
       if (tap == 0) dma_planes(c + 1);
-      dma_w((it0 + tap + NS - 1) % NS);
+      dma_w((it0 + tap + NS - 1) % NS, it0 + tap + NS - 1);
       compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
       __builtin_amdgcn_sched_barrier(0);
-      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
+      // slab it+1 must have landed: younger than it are the NS-2 slabs of the iterations since, plus the plane batches
+      // issued in those iterations (at their tap 0); the last tap of a chunk also needs the next chunk's planes,
+      // which only the slabs of this chunk are younger than
+      constexpr int planes_in_flight = [] { int n = 0; for (int k = 0; k <= NS - 3; ++k) n += (((tap - k) % TAPS + TAPS) % TAPS) == 0; return n; }();
+      constexpr int allow = (NS - 2) * BG + planes_in_flight * HG;
+      constexpr int allow_last = TAPS * BG < allow ? TAPS * BG : allow;
+      wait_vm<(tap == TAPS - 1) ? allow_last : allow>();
       __builtin_amdgcn_s_barrier();
     });
   }
-  {
-    const char* Ab = ldsA + (c & 1) * A_BYTES;
-    const int it0 = c * TAPS;
-    static_for<TAPS>([&](auto tapc) {
-      constexpr int tap = decltype(tapc)::value;
-      if (tap + NS - 1 < TAPS) dma_w((it0 + tap + NS - 1) % NS);
-      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap + NS - 1 < TAPS) wait_vm<(NS - 2) * BG>(); else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-    });
-  }
+  wait_vm<0>();
   // fp32 partial tile -> kpart[zk][output pixel][C]
   const long out_pix = MODE == 2 ? 4L * npix : (long)npix;
   float* const kpz = a.kpart + (long)zk * out_pix * a.Cout;
@@ -1349,10 +1349,15 @@ __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
   }
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, int NS = 8>
 int launch_convflat(Conv3x3Args& a, hipStream_t s) {
-  constexpr int lds = 2 * 4 * 128 * 64 + 4 * BN * 64;
-  auto kern = convflat_dma16_kernel<BN, MODE>;
+  constexpr int lds = 2 * 4 * 128 * 64 + NS * BN * 64;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (NS == 8) {       // S2S_FLAT_NS=4: the 3-tap ring of the windowed kernels, for A/B measurements
+    static const int ns_env = [] { const char* e = getenv("S2S_FLAT_NS"); return e ? atoi(e) : 8; }();
+    if (ns_env == 4) return launch_convflat<BN, MODE, 4>(a, s);
+  }
+  auto kern = convflat_dma16_kernel<BN, MODE, NS>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   const int npix = a.B << (a.lgh + a.lgw);
