@@ -207,6 +207,140 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const T* __rest
   }
 }
 
+// ---- single-launch forms for small maps ------------------------------------------------------------------------------
+// Up to 32x32 pixels a (sample, 32-channel) slice is at most 64 KiB (bf16): one workgroup reads it twice (the second
+// time from L1 / L2), with the reduction in between done in LDS -- one launch instead of reduce + finalize + apply.  At
+// these sizes the three-launch form is bound by launch latency, not bandwidth (5-14 us per launch for < 10 MB), and the
+// inner U-Net levels and the PatchGAN's last layers run 14 such norms forward and backward per step.
+constexpr int IN_SMALL_HW = 1024;
+constexpr int IN_CG = 32;                      // channels per workgroup: 4 pieces x 64 pixel lanes
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ g, int ldg,
+                                                       const T* __restrict__ g2, int ldg2, T* __restrict__ y, int ldy,
+                                                       T* __restrict__ y2, int ldy2, float* __restrict__ stats, int B, int HW,
+                                                       int C, float eps, float slope) {
+  constexpr int PCB = IN_CG / 8, WL = 256 / PCB;
+  const int pc = threadIdx.x & (PCB - 1), wl = threadIdx.x / PCB;
+  const int n = blockIdx.y, c8 = blockIdx.x * IN_CG + pc * 8;
+  const bool live = c8 < C;
+  const long BC = (long)B * C, o = (long)n * C + c8;
+  const T* const xb = x + (long)n * HW * ldx + c8;
+  __shared__ double red[2][WL][IN_CG + 1];
+  __shared__ float fin[4][IN_CG];               // forward: mean, invstd, scale, shift; backward: k1, k2 in rows 0, 1
+  float mu[8], is[8], sc[8], sh[8];
+  if (BWD && live) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu[k] = stats[o + k]; is[k] = stats[BC + o + k]; sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
+  }
+  float s1[8], s2[8], shift0[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; shift0[k] = 0.f; }
+  if (live && !BWD) {
+    // shifted sums: sum(x - K), sum((x - K)^2) with K = the channel's first pixel.  E[x^2] - mean^2 loses everything
+    // when the spread of a small map is far below its level (a 2-pixel map with var ~ eps); shifting by a value of the
+    // data removes that cancellation at no cost
+    const f32x8 v0 = load8(xb);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) shift0[k] = v0.v[k];
+  }
+  if (live) {
+    for (int p = wl; p < HW; p += WL) {
+      f32x8 v = load8(xb + (long)p * ldx);
+      if (!BWD) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v.v[k] -= shift0[k];
+      }
+      if (BWD) {
+        const f32x8 gv = load8(g + ((long)n * HW + p) * ldg + c8);
+        f32x8 gw;
+        if (g2) gw = load8(g2 + ((long)n * HW + p) * ldg2 + c8);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gw.v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw.v[k] : slope * gv.v[k];
+          s1[k] += dz;
+          s2[k] = fmaf(dz, (v.v[k] - mu[k]) * is[k], s2[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] += v.v[k]; s2[k] = fmaf(v.v[k], v.v[k], s2[k]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][wl][pc * 8 + k] = (double)s1[k]; red[1][wl][pc * 8 + k] = (double)s2[k]; }
+  if (!BWD && wl == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fin[0][pc * 8 + k] = shift0[k];           // K per channel, read back by the finalising lane
+  }
+  __syncthreads();
+  if (threadIdx.x < IN_CG) {
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < WL; ++r) { a += red[0][r][threadIdx.x]; b += red[1][r][threadIdx.x]; }
+    const int c = blockIdx.x * IN_CG + threadIdx.x;
+    if (BWD) {
+      fin[0][threadIdx.x] = (float)a / (float)HW;            // as the three-launch form: float sums, then * 1/HW
+      fin[1][threadIdx.x] = (float)b / (float)HW;
+    } else {
+      const double ms = a / (double)HW;                       // mean of the shifted values
+      double var = b / (double)HW - ms * ms;
+      if (var < 0.0) var = 0.0;
+      const double mean = ms + (double)fin[0][threadIdx.x];
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      fin[0][threadIdx.x] = (float)mean; fin[1][threadIdx.x] = invstd;
+      fin[2][threadIdx.x] = invstd; fin[3][threadIdx.x] = -(float)mean * invstd;
+      if (c < C) {
+        const long i = (long)n * C + c;
+        stats[i] = (float)mean; stats[BC + i] = invstd; stats[2 * BC + i] = invstd; stats[3 * BC + i] = -(float)mean * invstd;
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  if (BWD) {
+    float k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { k1[k] = fin[0][pc * 8 + k]; k2[k] = fin[1][pc * 8 + k]; }
+    for (int p = wl; p < HW; p += WL) {
+      const f32x8 v = load8(xb + (long)p * ldx);
+      const f32x8 gv = load8(g + ((long)n * HW + p) * ldg + c8);
+      f32x8 gw;
+      if (g2) gw = load8(g2 + ((long)n * HW + p) * ldg2 + c8);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gw.v[k] = 0.f;
+      }
+      f32x8 o8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw.v[k] : slope * gv.v[k];
+        o8.v[k] = sc[k] * (dz - k1[k] - ((v.v[k] - mu[k]) * is[k]) * k2[k]);
+      }
+      store8(y + ((long)n * HW + p) * ldy + c8, o8);
+    }
+  } else {
+    float fs[8], fh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { fs[k] = fin[2][pc * 8 + k]; fh[k] = fin[3][pc * 8 + k]; }
+    for (int p = wl; p < HW; p += WL) {
+      const f32x8 v = load8(xb + (long)p * ldx);
+      f32x8 o8, r8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = fmaf(v.v[k], fs[k], fh[k]);
+        o8.v[k] = z > 0.f ? z : slope * z;
+        r8.v[k] = fmaxf(z, 0.f);
+      }
+      store8(y + ((long)n * HW + p) * ldy + c8, o8);
+      if (y2) store8(y2 + ((long)n * HW + p) * ldy2 + c8, r8);
+    }
+  }
+}
+
 inline int in_blocks(int B, int H, int W, int C) {
   const int pcb = in_pcb(C), wl = 256 / pcb, groups = cdiv(C / 8, pcb);
   const long hw = (long)H * W;
@@ -241,6 +375,18 @@ extern "C" int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const 
   if ((long)H * W <= 1) return S2S_ERR_SHAPE;      // torch raises for a single spatial element in training mode
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
+  if (!gamma && HW <= IN_SMALL_HW) {            // small maps: one launch (in_small_kernel)
+    const dim3 sg(cdiv(C, IN_CG), B);
+    if (dtype == S2S_BF16)
+      hipLaunchKernelGGL((in_small_kernel<bf16_t, false>), sg, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0,
+                         (const bf16_t*)nullptr, 0, (bf16_t*)y, ldy, (bf16_t*)y2, ldy2, stats, B, HW, C, eps, slope);
+    else if (dtype == S2S_F32)
+      hipLaunchKernelGGL((in_small_kernel<float, false>), sg, dim3(256), 0, s, (const float*)x, ldx, (const float*)nullptr, 0,
+                         (const float*)nullptr, 0, (float*)y, ldy, (float*)y2, ldy2, stats, B, HW, C, eps, slope);
+    else return S2S_ERR_DTYPE;
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+  }
   const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, B);
   const unsigned fin = (unsigned)(((long)B * C + 3) / 4);
 #define S2S_IN_FWD(TT)                                                                                              \
@@ -274,6 +420,20 @@ extern "C" int s2s_instnorm_lrelu_bwd2(int dtype, const void* g, int ldg, const 
   if (!in_args_ok(B, H, W, C, ldx, ldg) || (lddx % 8) || (g2 && (ldg2 % 8))) return S2S_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
+  if (!dgamma && HW <= IN_SMALL_HW) {           // small maps: one launch (in_small_kernel)
+    const dim3 sg(cdiv(C, IN_CG), B);
+    if (dtype == S2S_BF16)
+      hipLaunchKernelGGL((in_small_kernel<bf16_t, true>), sg, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)g, ldg,
+                         (const bf16_t*)g2, ldg2, (bf16_t*)dx, lddx, (bf16_t*)nullptr, 0, const_cast<float*>(stats), B, HW, C,
+                         0.f, slope);
+    else if (dtype == S2S_F32)
+      hipLaunchKernelGGL((in_small_kernel<float, true>), sg, dim3(256), 0, s, (const float*)x, ldx, (const float*)g, ldg,
+                         (const float*)g2, ldg2, (float*)dx, lddx, (float*)nullptr, 0, const_cast<float*>(stats), B, HW, C,
+                         0.f, slope);
+    else return S2S_ERR_DTYPE;
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+  }
   float* const part = work;                                   // [2][B*C][nb]
   float* const cs = work + (size_t)2 * B * C * nb;            // [2][B][C]
   const dim3 grid(cdiv(C / 8, in_pcb(C)), nb, B);
