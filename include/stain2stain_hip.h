@@ -53,6 +53,14 @@ int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1,
 /* Diagnostic: with S2S_CONV_DBG=64 in the environment the bf16 kernel's workgroups record the shader-clock counter and
  * the 100 MHz wall clock at entry and exit; this copies {clk0, clk1, wall0, wall1} of the first n <= 8192 workgroups of
  * the last launch into a HOST buffer (scripts/clk_probe.py turns them into the MHz the kernel ran at). */
+/* The same with a split-K workspace (optional): kwork = float[s2s_conv3x3_ksplit()][B*H*W][Cout]; when the launch
+ * carries no statistics and has few output tiles (sampling one tile at a time) the 32-channel chunks are shared by
+ * several workgroups and a second launch folds the fp32 partial tiles (+ bias, folded affine, ReLU). */
+int s2s_conv3x3_ksplit(int dtype, int B, int H, int W, int Cout, int cin);
+int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                       const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                       const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H, int W,
+                       int Cout, void* stream);
 int s2s_debug_conv_clock(long* out_host, int n);
 
 /* ---- 3x3 convolution weight gradient (conv3x3_wgrad_mfma.hip) -----------------------------------

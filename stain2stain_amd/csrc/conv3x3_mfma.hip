@@ -808,6 +808,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   const int y0 = ty * TH, x0p = tx * TW;
   const int n0 = blockIdx.y * BN;
   const int ctot = a.c0 + a.c1;
+  // split-K (small batches: sampling one tile at a time leaves a 16x16 level with 32 workgroups and 288 taps each):
+  // gridDim.z workgroups share the tile, each takes a range of the chunks and leaves an fp32 partial tile
+  const int c_lo = (int)(((long)blockIdx.z * a.nchunk) / gridDim.z), c_hi = (int)(((long)(blockIdx.z + 1) * a.nchunk) / gridDim.z);
 
   const int drow = lane >> 2, dslot = lane & 3;
   int apix[HG], apc[HG];
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   for (int j = 0; j < BG; ++j) {
     const int n = (wave + 4 * j) * 16 + drow;
     const bool ok = n0 + n < a.Cout;
-    wptr[j] = ok ? wp + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
+    wptr[j] = ok ? wp + (long)c_lo * 9 * a.Cout * 64 + ((long)(n0 + n) * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2 : g_zero_page;
     wstep[j] = ok ? a.Cout * 64 : 0;
   }
   auto dma_halo = [&](int c) {
@@ -886,16 +889,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       for (int ni = 0; ni < NI; ++ni)   // weights as A, pixels as B: the result tile is [channel][pixel] (see the epilogue)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
   };
-  dma_halo(0);
+  dma_halo(c_lo);
   static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  int c = 0;
-  if (a.dbg & 32) c = a.nchunk - 1;
-  for (; c + 1 < a.nchunk; ++c) {
+  int c = c_lo;
+  for (; c + 1 < c_hi; ++c) {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
-    const int it0 = c * 9;
+    const int it0 = (c - c_lo) * 9;
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
       if (tap == 0) dma_halo(c + 1);
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     }
   {
     const char* Ab = ldsA + (c & 1) * A_BYTES;
-    const int it0 = c * 9;
+    const int it0 = (c - c_lo) * 9;
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
       if (tap + NS - 1 < 9) dma_w((it0 + tap + NS - 1) % NS);
@@ -928,6 +930,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     });
   }
   if (a.dbg & 16) return;
+  if (a.kpart) {
+    float* const kpz = a.kpart + (long)blockIdx.z * ((long)a.B * a.H * a.W) * a.Cout;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = wm * WTM + mi * 16 + cl;
+      const int py = m / TW, px = m - py * TW;
+      const int gy = y0 + py, gx = x0p + px;
+      if (gy < a.H && gx < a.W) {
+        float* const row = kpz + (((long)img * a.H + gy) * a.W + gx) * a.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = n0 + wn * WTN + ni * 16 + 4 * kp;
+          if (n < a.Cout) *reinterpret_cast<f32x4*>(row + n) = acc[mi][ni];
+        }
+      }
+    }
+    return;
+  }
   const OutMap om{1, 0, 0, a.H, a.W};
   if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
@@ -945,7 +965,8 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   auto kern = conv3x3_dma16_kernel<TH, TW, BN, WM, WN, NS>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
-  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN));
+  if (!a.kpart) a.ksplit = 1;
+  dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -1386,6 +1407,10 @@ __global__ __launch_bounds__(256) void convk_splitk_reduce_kernel(Conv3x3Args a,
     f32x8 r;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      if (a.ep_scale) {                                  // eval-mode BatchNorm folded behind the 3x3 convolution
+        acc.v[k] = fmaf(acc.v[k], a.ep_scale[n + k], a.ep_shift[n + k]);
+        if (a.relu) acc.v[k] = fmaxf(acc.v[k], 0.f);
+      }
       if (a.act) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : a.act_slope * acc.v[k];
       r.v[k] = fmaxf(acc.v[k], 0.f);
     }
@@ -1687,10 +1712,41 @@ extern "C" int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout)
   return B * cdiv(H, c.th) * cdiv(W, c.tw);
 }
 
+extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                                  const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                                  const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
+                                  int W, int Cout, void* stream);
+
+// Split count of s2s_conv3x3_nhwc_k for a launch without statistics (bf16; 1 = not split): at small batch the deep
+// levels have a few dozen output tiles and K = 9 x 512..1536, so the chunk range is shared by up to 16 workgroups.
+// kwork: float[splits][B*H*W][Cout].
+extern "C" int s2s_conv3x3_ksplit(int dtype, int B, int H, int W, int Cout, int cin) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16) return 1;
+  static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
+  if (use_dma != 16) return 1;
+  const TileCfg& c = kBf16Cfg[select_cfg(dtype, B, H, W, Cout)];
+  const long base = cfg_blocks(c, B, H, W, Cout);
+  const int nchunk = cdiv(cin, 32);
+  if (base >= 128 || nchunk < 8) return 1;
+  long sp = (512 + base - 1) / base;
+  if (sp > nchunk / 4) sp = nchunk / 4;
+  if (sp > 16) sp = 16;
+  return sp < 2 ? 1 : (int)sp;
+}
+
 extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
                                 const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
                                 const float* ep_scale, const float* ep_shift, int relu, int B, int H, int W,
                                 int Cout, void* stream) {
+  return s2s_conv3x3_nhwc_k(dtype, x0, ld0, c0, x1, ld1, c1, w_packed, bias, y, ldy, stat_part, ep_scale, ep_shift, relu,
+                            nullptr, B, H, W, Cout, stream);
+}
+
+extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                                  const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                                  const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
+                                  int W, int Cout, void* stream) {
   if (!x0 || !w_packed || !y) return S2S_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
   if ((c0 % 8) || (c1 % 8) || (ld0 % 8) || (ld1 % 8) || (c1 > 0 && !x1)) return S2S_ERR_SHAPE;
@@ -1708,7 +1764,16 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
   { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
-  return dispatch(dtype, a, s);
+  a.ksplit = (kwork && !stat_part) ? s2s_conv3x3_ksplit(dtype, B, H, W, Cout, c0 + c1) : 1;
+  a.kpart = a.ksplit > 1 ? kwork : nullptr;
+  const int rc = dispatch(dtype, a, s);
+  if (rc != S2S_OK || !a.kpart) return rc;
+  const long npix = (long)B * H * W, pieces = npix * (Cout / 8);
+  long nb = (pieces + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(convk_splitk_reduce_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, a, npix);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }
 
 // ---- KS x KS-tap convolutions of row a13 -------------------------------------------------------------------------

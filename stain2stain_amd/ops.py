@@ -165,8 +165,13 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     if want_stats:
         nb = _L().s2s_conv3x3_stat_blocks(dt, B, H, W, cout)
         stat = torch.empty((2, cout, nb), dtype=torch.float32, device=x0.device)
-    rc = _L().s2s_conv3x3_nhwc(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
-                               _f32(scale), _f32(shift), int(relu), B, H, W, cout, _stream())
+    kwork = None
+    if not want_stats:                    # few output tiles (small batches): the chunk range is split over workgroups
+        nsplit = _L().s2s_conv3x3_ksplit(dt, B, H, W, cout, c0 + c1)
+        if nsplit > 1:
+            kwork = torch.empty((nsplit, B * H * W, cout), dtype=torch.float32, device=x0.device)
+    rc = _L().s2s_conv3x3_nhwc_k(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
+                                 _f32(scale), _f32(shift), int(relu), _f32(kwork), B, H, W, cout, _stream())
     _native.check(rc, "conv3x3")
     return out, stat
 

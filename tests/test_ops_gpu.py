@@ -82,6 +82,32 @@ def test_conv3x3_epilogue_affine_relu(dtype):
     assert relerr(nchw(y), ref) < tol_act(dtype)
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16, 512, 256, 192), (2, 8, 8, 256, 0, 64), (1, 32, 32, 320, 0, 256)])
+def test_conv3x3_split_k_small_batch(case):
+    """Small batches (the reference samples one tile at a time): few output tiles, deep K -- the launch is split over
+    the 32-channel chunks and a second launch folds the fp32 partial tiles with bias, folded eval-mode BatchNorm and ReLU.
+    Plain (bias only) and fused-epilogue forms, two sources, against torch on bf16-rounded operands."""
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout = case
+    dtype = torch.bfloat16
+    assert ops._L().s2s_conv3x3_ksplit(0, B, H, W, cout, c0 + c1) > 1
+    g = torch.Generator().manual_seed(18)
+    x = torch.rand(B, c0 + c1, H, W, generator=g) * 2 - 1
+    w = (torch.rand(cout, c0 + c1, 3, 3, generator=g) * 2 - 1) * 0.05
+    b = torch.rand(cout, generator=g) - 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.rand(cout, generator=g) - 0.5
+    conv = F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    xs = nhwc(x, dtype)
+    x0, x1 = xs[..., :c0], (xs[..., c0:] if c1 else None)
+    wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
+    y, _ = ops.conv3x3(x0, x1, wf, b.to(DEV), cout)
+    assert relerr(nchw(y), conv) < tol_act(dtype)
+    y, _ = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    assert relerr(nchw(y), (conv * sc[None, :, None, None] + sh[None, :, None, None]).clamp_min(0)) < tol_act(dtype)
+    _, st = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, want_stats=True)            # statistics: never split
+    assert st is not None and relerr(st[0].sum(1).cpu(), rnd(conv, dtype).sum((0, 2, 3))) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3_dgrad(case, dtype):
