@@ -70,6 +70,10 @@ int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout);
 int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
                            const void* x1, int ld1, int c1, float* part, float* grad_oihw, int accumulate,
                            int B, int H, int W, void* stream);
+/* the same in two launches: phases = 1 the split MFMA kernel (slabs into part), 2 the fold into grad_oihw, 3 both */
+int s2s_conv3x3_wgrad_phase(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
+                            const void* x1, int ld1, int c1, float* part, float* grad_oihw, int accumulate,
+                            int B, int H, int W, int phases, void* stream);
 
 /* ---- stem and head (conv_edge.hip) ----------------------------------------------------------------
  * stem: first conv of SharedEncoder.inc (shared_encoder.py:15,67), NCHW fp32 image (Cin <= 6: RGB, or RGB + the

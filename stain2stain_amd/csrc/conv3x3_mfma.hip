@@ -61,6 +61,10 @@ struct Conv3x3Args {
   int lgh, lgw;   // convflat_dma16_kernel: log2 of the map size the flattened pixel index is decoded with
   int bias_mod;   // bias index = channel % bias_mod (= Cout normally; Cout / 4 for the transposed 4x4 layers, whose four
                   // sub-pixel channel groups share one bias vector)
+  // XCD-aware workgroup order (conv3x3_dma16_kernel): workgroups are dealt to the 8 XCDs round-robin by linear id and
+  // every XCD has its own L2, so the grid is cut into xsp x xsn = 8 blocks (pixel-tile ranges x output-channel-tile
+  // ranges), one per XCD, walked output-channel tile fastest; xsp = 0 = the plain order.
+  int xsp, xsn;
   int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
 };
 
@@ -801,12 +805,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   const int wm = wave / WN, wn = wave % WN;
   const int cl = lane & 15, kp = lane >> 4;           // fragment row / 16-B piece (k group)
 
-  int bt = blockIdx.x;
+  int bt = blockIdx.x, by = blockIdx.y;
+  if (a.xsp) {       // this workgroup runs on XCD (linear id % 8): give it a tile of that XCD's block of the grid
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = L & 7, k = L >> 3;
+    const unsigned xp = xcd % (unsigned)a.xsp, xn = xcd / (unsigned)a.xsp;
+    const unsigned P = gridDim.x / (unsigned)a.xsp, Nn = gridDim.y / (unsigned)a.xsn;
+    const unsigned kp_ = k / Nn, kn_ = k - kp_ * Nn;
+    bt = (int)(xp * P + kp_); by = (int)(xn * Nn + kn_);
+  }
+  const int tile_id = bt;
   const int tx = bt % a.tilesX; bt /= a.tilesX;
   const int ty = bt % a.tilesY;
   const int img = bt / a.tilesY;
   const int y0 = ty * TH, x0p = tx * TW;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
   const int ctot = a.c0 + a.c1;
   // split-K (small batches: sampling one tile at a time leaves a 16x16 level with 32 workgroups and 288 taps each):
   // gridDim.z workgroups share the tile, each takes a range of the chunks and leaves an fp32 partial tile
@@ -949,8 +962,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     return;
   }
   const OutMap om{1, 0, 0, a.H, a.W};
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
-  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, blockIdx.x, om);
+  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
+  else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
   if ((a.dbg & 64) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4 + 0] = c0_; g_clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter(); g_clk[blockIdx.x * 4 + 2] = w0_; g_clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
 
@@ -967,6 +980,20 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   if (!a.kpart) a.ksplit = 1;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit);
+  static const int xcd_aware = [] { const char* e = getenv("S2S_CONV_XCD"); return e ? atoi(e) : 1; }();
+  a.xsp = 0; a.xsn = 1;
+  if (xcd_aware && a.ksplit == 1 && ((long)grid.x * grid.y) % 8 == 0) {
+    // bytes the 8 L2s fetch between them: an XCD reads the activations of its pixel range and the weights of its
+    // channel range, so the grid cut (sp pixel ranges x sn channel ranges) costs sn * |activations| + sp * |weights|
+    const double act = 2.0 * a.B * a.H * a.W * (a.c0 + a.c1), wb = 2.0 * 9 * (a.c0 + a.c1) * a.Cout;
+    double best = 0;
+    for (int sp = 8; sp >= 1; sp >>= 1) {
+      const int sn = 8 / sp;
+      if (grid.x % sp || grid.y % sn) continue;
+      const double cost = sn * act + sp * wb;
+      if (!a.xsp || cost < best) { best = cost; a.xsp = sp; a.xsn = sn; }
+    }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -1682,7 +1709,7 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
 // stem forward, called from s2s_stem_conv3x3_fwd (conv_edge.hip); statistics rows = B * ceil(H/16) * ceil(W/16)
 int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, const float* bias, void* y, int ldy,
                           float* stat_part, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
-  Conv3x3Args a;
+  Conv3x3Args a{};
   a.x0 = a.x1 = a.w = nullptr; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout;
   a.ld0 = a.c0 = a.ld1 = a.c1 = 0; a.ldy = ldy;
@@ -1755,7 +1782,7 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
   if ((ep_scale == nullptr) != (ep_shift == nullptr)) return S2S_ERR_NULL;
   const uintptr_t al = 15;
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
-  Conv3x3Args a;
+  Conv3x3Args a{};
   a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0; a.lgh = a.lgw = 0;
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
@@ -1825,7 +1852,7 @@ extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, cons
   if (H + ks - 1 - 2 * pad < 1 || W + ks - 1 - 2 * pad < 1) return S2S_ERR_SHAPE;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return S2S_ERR_ALIGN;
   if ((long)B * (H + 3) * (W + 3) >= (1L << 31)) return S2S_ERR_SHAPE;     // 32-bit pixel index in the halo loader
-  Conv3x3Args a;
+  Conv3x3Args a{};
   a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
   a.bias_mod = bias_mod > 0 ? bias_mod : Cout;
@@ -1956,7 +1983,7 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
   if (y2 && ((ldy2 % 8) || ldy2 < Cout)) return S2S_ERR_SHAPE;
   if (H >= 32768 || W >= 32768 || (long)B * 4 * H * W >= (1L << 31)) return S2S_ERR_SHAPE;     // 16-bit cell coordinates in the loader
   if (((uintptr_t)x & 15) || ((uintptr_t)wf & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return S2S_ERR_ALIGN;
-  Conv3x3Args a;
+  Conv3x3Args a{};
   a.x0 = x; a.x1 = nullptr; a.w = wf; a.bias = bias; a.y = y; a.stat_part = nullptr;
   a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
   a.bias_mod = Cout; a.lgc = __builtin_ctz((unsigned)Cin);
@@ -2003,7 +2030,7 @@ extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, c
   if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C % 64) || Cin <= 0 || (Cin % 8) || (ldx % 8) || ldx < Cin || (ldy % 8) || ldy < C) return S2S_ERR_SHAPE;
   if ((long)B * 4 * h * w >= (1L << 31)) return S2S_ERR_SHAPE;
   if (((uintptr_t)x & 15) || ((uintptr_t)wd & 15) || ((uintptr_t)y & 15)) return S2S_ERR_ALIGN;
-  Conv3x3Args a;
+  Conv3x3Args a{};
   a.x0 = x; a.x1 = nullptr; a.w = wd; a.bias = bias; a.y = y; a.stat_part = nullptr;
   a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8;
   a.bias_mod = C; a.lgc = 0;

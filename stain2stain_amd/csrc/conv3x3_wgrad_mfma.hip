@@ -31,6 +31,8 @@ struct WgradArgs {
   int B, H, W, tilesY, tilesX, ntiles, S;
   int lgc;   // conv2x2_wgrad_dma_kernel<.., S2D = true>: log2 of the real channel count of the plain X tensor
   int lgh, lgw;   // conv2x2_wgrad_flat_kernel: log2 of the (output) map size
+  int xcd;        // conv3x3_wgrad_dma_kernel: 1 = XCD-aware workgroup order (an XCD takes a contiguous range of the
+                  // (pixel split, co tile, ci tile) sequence, so the workgroups that stream the same dY / X tiles share an L2)
 };
 
 namespace {
@@ -247,18 +249,25 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
 //         taps of their row and stage only the TH halo rows they need.  Three times the workgroups for the same
 //         number of pixel splits, i.e. a third of the partial-slab traffic for the same machine fill -- used for
 //         the layers with few (co,ci) tiles, where the slabs, not the MFMAs, set the time.
-template <int TH, int TW, int NT>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
+// KHW (with NT = 3): the three kh rows go to three 4-wave TEAMS of one 12-wave workgroup instead.  The teams share
+//         one staged dY tile and one full halo, a wave holds 48 accumulators (three waves per SIMD), and the machine is
+//         filled by 256 workgroups instead of 512 -- half the pixel splits, i.e. half the partial-slab bytes written at
+//         the end of the kernel (when every workgroup stores at once and the MFMAs idle) and read back by the reduce.
+template <int TH, int TW, int NT, bool KHW = false>
+__global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
   using T = bf16_t;
+  static_assert(!KHW || NT == 3, "teams own one kernel row each");
+  constexpr int NW = KHW ? 12 : 4;
   constexpr int NPX = TH * TW;                             // 128
-  constexpr int HW_ = TW + 2, HR = (NT == 9) ? TH + 2 : TH, HALO = HR * HW_;
+  constexpr int HW_ = TW + 2, HR = (NT == 9 || KHW) ? TH + 2 : TH, HALO = HR * HW_;
   constexpr int XROWS = (HALO + 31) / 32 * 32;             // 192 / 160 (whole DMA groups, 4 waves x 2 halves)
   constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
-  constexpr int DYG = 2 * NPX / 16 / 4;                    // dY DMA instr per wave (4)
-  constexpr int XG = 2 * XROWS / 16 / 4;                   // halo DMA instr per wave (6 / 5)
+  constexpr int DYGRP = 2 * NPX / 16, XGRP = 2 * XROWS / 16;   // 16-row DMA groups per tile (16 / 24 or 20)
+  constexpr int DYG = (DYGRP + NW - 1) / NW;               // dY DMA instr per wave (4; 2 with twelve waves)
+  constexpr int XG = (XGRP + NW - 1) / NW;                 // halo DMA instr per wave (6 / 5; 2)
   constexpr int BUF = DY_BYTES + X_BYTES;
   constexpr int KSTEPS = NPX / 16;
-  static_assert((2 * NPX / 16) % 4 == 0 && (2 * XROWS / 16) % 4 == 0, "DMA groups split evenly over 4 waves");
+  static_assert(KHW || (DYGRP % 4 == 0 && XGRP % 4 == 0), "DMA groups split evenly over 4 waves");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
   const T* __restrict__ dy = static_cast<const T*>(a.dy);
@@ -267,12 +276,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave >> 1, wci = wave & 1;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int wco = (wave & 3) >> 1, wci = wave & 1;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {     // workgroups go to the 8 XCDs round-robin by linear id: XCD x takes logical ids [x N/8, (x+1) N/8)
+    const unsigned L = bx + gridDim.x * (by + gridDim.y * bz), per = gridDim.x * gridDim.y * gridDim.z / 8;
+    unsigned Lq = (L & 7) * per + (L >> 3);
+    bx = Lq % gridDim.x; Lq /= gridDim.x;
+    by = Lq % gridDim.y; bz = Lq / gridDim.y;
+  }
+  const int ci0 = bx * 64, co0 = by * 64;
   const int cin = a.c0 + a.c1;
   const int drow = lane >> 2, dslot = lane & 3;
-  const int kh0 = (NT == 9) ? 0 : (int)(blockIdx.z % 3);
-  const int zsplit = (NT == 9) ? (int)blockIdx.z : (int)(blockIdx.z / 3);
+  const int kh0 = (NT == 9) ? 0 : KHW ? (wave >> 2) : (int)(bz % 3);
+  const int khx = KHW ? 0 : kh0;                            // first kernel row of the staged halo
+  const int zsplit = (NT == 9 || KHW) ? (int)bz : (int)(bz / 3);
 
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   bool dy_ok[DYG];
 #pragma unroll
   for (int j = 0; j < DYG; ++j) {
-    const int grp = wave + 4 * j;                  // half = grp / 8, rows (grp % 8) * 16 ..
+    const int grp = wave + NW * j;                 // half = grp / 8, rows (grp % 8) * 16 ..
     const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
     const int co = co0 + half * 32 + dslot * 8;
     dy_py[j] = px / TW; dy_px[j] = px - dy_py[j] * TW;
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   int x_off[XG], x_ld[XG], x_hy[XG], x_hx[XG];
 #pragma unroll
   for (int j = 0; j < XG; ++j) {
-    const int grp = wave + 4 * j;
+    const int grp = wave + NW * j;
     const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
     const int ci = ci0 + half * 32 + dslot * 8;
     x_hy[j] = px / HW_; x_hx[j] = px - x_hy[j] * HW_;
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
       if (ci < a.c0) { x_ptr[j] = x0 + ci; x_ld[j] = a.ld0; }
       else if (ci < cin) { x_ptr[j] = x1 + (ci - a.c0); x_ld[j] = a.ld1; }
     }
-    x_off[j] = ((x_hy[j] - 1 + kh0) * a.W + (x_hx[j] - 1)) * x_ld[j];
+    x_off[j] = ((x_hy[j] - 1 + khx) * a.W + (x_hx[j] - 1)) * x_ld[j];
   }
 
   auto dma_tile = [&](int tile, int buf) {
@@ -326,28 +343,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
     if (interior) {
 #pragma unroll
       for (int j = 0; j < DYG; ++j) {
+        if (KHW && wave + NW * j >= DYGRP) break;                       // wave-uniform
         const void* src = dy_ok[j] ? (const void*)(dy + pixbase * a.lddy + dy_off[j]) : (const void*)g_wgrad_zero_page;
-        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + NW * j) * 1024));
       }
 #pragma unroll
       for (int j = 0; j < XG; ++j) {
+        if (KHW && wave + NW * j >= XGRP) break;
         const void* src = x_ptr[j] ? (const void*)(x_ptr[j] + pixbase * x_ld[j] + x_off[j]) : (const void*)g_wgrad_zero_page;
-        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + NW * j) * 1024));
       }
     } else {
 #pragma unroll
       for (int j = 0; j < DYG; ++j) {
+        if (KHW && wave + NW * j >= DYGRP) break;
         const int gy = y0 + dy_py[j], gx = xs + dy_px[j];
         const void* src = g_wgrad_zero_page;
         if (gy < a.H && gx < a.W && dy_ok[j]) src = dy + pixbase * a.lddy + dy_off[j];
-        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + NW * j) * 1024));
       }
 #pragma unroll
       for (int j = 0; j < XG; ++j) {
-        const int gy = y0 - 1 + kh0 + x_hy[j], gx = xs - 1 + x_hx[j];
+        if (KHW && wave + NW * j >= XGRP) break;
+        const int gy = y0 - 1 + khx + x_hy[j], gx = xs - 1 + x_hx[j];
         const void* src = g_wgrad_zero_page;
         if (x_ptr[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = x_ptr[j] + pixbase * x_ld[j] + x_off[j];
-        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + 4 * j) * 1024));
+        dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + NW * j) * 1024));
       }
     }
   };
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) 
   for (; tile < a.ntiles; tile += a.S) {
     if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);   // lands during the MFMAs below
     const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
-    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off + (KHW ? kh0 * (HW_ * 64) : 0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int m0 = ks * 16;
@@ -447,29 +468,32 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   return S2S_OK;
 }
 
-template <int TH, int TW, int NT>
+template <int TH, int TW, int NT, bool KHW = false>
 int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
-  constexpr int XROWS = (((NT == 9) ? TH + 2 : TH) * (TW + 2) + 31) / 32 * 32;
+  constexpr int XROWS = (((NT == 9 || KHW) ? TH + 2 : TH) * (TW + 2) + 31) / 32 * 32;
   constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   a.ntiles = a.B * a.tilesY * a.tilesX;
   if (a.S > a.ntiles) return S2S_ERR_SHAPE;
-  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT>;
+  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT, KHW>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
-  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * (NT == 9 ? 1 : 3));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * ((NT == 9 || KHW) ? 1 : 3));
+  static const int xcd_aware = [] { const char* e = getenv("S2S_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+  a.xcd = xcd_aware && ((long)grid.x * grid.y * grid.z) % 8 == 0;
+  hipLaunchKernelGGL(kern, grid, dim3(KHW ? 768 : 256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
 
-// layers with at most this many 64x64 (co,ci) tiles split the kh rows over workgroups (bf16 DMA kernel)
+// how the nine taps are spread (bf16 DMA kernel): 0 = nine per wave, 1 = the kh rows over three workgroups, 2 = the kh
+// rows over the three 4-wave teams of a 12-wave workgroup
 inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
   static const int mode = [] { const char* e = getenv("S2S_WGRAD_KH"); return e ? atoi(e) : -1; }();
   if (dtype != S2S_BF16) return 0;
   if (mode >= 0) return mode;
-  return 0;   // re-measured after the reduce kernel was widened: nine taps per workgroup win by 8% even at 64->64
+  return 0;   // 1 re-measured after the reduce kernel was widened: nine taps per workgroup win by 8% even at 64->64
 }
 
 // =========================================================================================================
@@ -1072,8 +1096,10 @@ int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
 extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = wgrad_ntiles(B, H, W);
-  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (wgrad_kh_split(dtype, Cin, Cout) ? 3 : 1);
-  static const int target = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  const int khm = wgrad_kh_split(dtype, Cin, Cout);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (khm == 1 ? 3 : 1);
+  static const int target_env = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int target = target_env ? target_env : (khm == 2 ? 256 : 512);   // one 12-wave or two 4-wave workgroups per CU
   // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
   // slab, so the two-tile layers stop at 320 splits (a single-tile layer takes all 512)
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
@@ -1085,27 +1111,35 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   return s;
 }
 
-extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
-                                      const void* x1, int ld1, int c1, float* part, float* grad_oihw,
-                                      int accumulate, int B, int H, int W, void* stream) {
+// phases: 1 = the split MFMA kernel (partial slabs into `part`), 2 = the fold of the slabs into the OIHW gradient,
+// 3 = both.  Two calls with phases 1 and 2 equal one call with 3; a profiler uses them to time the two kernels apart.
+extern "C" int s2s_conv3x3_wgrad_phase(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
+                                       const void* x1, int ld1, int c1, float* part, float* grad_oihw,
+                                       int accumulate, int B, int H, int W, int phases, void* stream) {
   if (!dy || !x0 || !part || !grad_oihw) return S2S_ERR_NULL;
+  if (phases < 1 || phases > 3) return S2S_ERR_SHAPE;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
   if ((Cout % 8) || (c0 % 8) || (c1 % 8) || (lddy % 8) || (ld0 % 8) || (ld1 % 8) || (c1 > 0 && !x1)) return S2S_ERR_SHAPE;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x0 & 15) || ((uintptr_t)x1 & 15)) return S2S_ERR_ALIGN;
-  WgradArgs a;
+  WgradArgs a{};
   a.dy = dy; a.x0 = x0; a.x1 = x1; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
   a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
   a.S = s2s_conv3x3_wgrad_splits(dtype, B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc;
+  int rc = S2S_OK;
   static const int use_dma = [] { const char* e = getenv("S2S_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-  if (dtype == S2S_BF16 && use_dma)
-    rc = wgrad_kh_split(dtype, c0 + c1, Cout) ? launch_wgrad_dma<8, 16, 3>(a, s) : launch_wgrad_dma<8, 16, 9>(a, s);
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+  if (!(phases & 1)) { if (a.S > wgrad_ntiles(B, H, W)) return S2S_ERR_SHAPE; }
+  else if (dtype == S2S_BF16 && use_dma)
+    switch (wgrad_kh_split(dtype, c0 + c1, Cout)) {
+      case 1: rc = launch_wgrad_dma<8, 16, 3>(a, s); break;
+      case 2: rc = launch_wgrad_dma<8, 16, 3, true>(a, s); break;
+      default: rc = launch_wgrad_dma<8, 16, 9>(a, s);
+    }
   else if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
-  else if (dtype == S2S_F32) rc = launch_wgrad<float, 8, 16>(a, s);
-  else return S2S_ERR_DTYPE;
-  if (rc != S2S_OK) return rc;
+  else rc = launch_wgrad<float, 8, 16>(a, s);
+  if (rc != S2S_OK || !(phases & 2)) return rc;
   const long n = (long)Cout * (c0 + c1);
   if (n <= 32768 && a.S >= 32)
     hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, part, grad_oihw,
@@ -1115,6 +1149,13 @@ extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
                        a.S, Cout, c0 + c1, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+extern "C" int s2s_conv3x3_wgrad_nhwc(int dtype, const void* dy, int lddy, int Cout, const void* x0, int ld0, int c0,
+                                      const void* x1, int ld1, int c1, float* part, float* grad_oihw,
+                                      int accumulate, int B, int H, int W, void* stream) {
+  return s2s_conv3x3_wgrad_phase(dtype, dy, lddy, Cout, x0, ld0, c0, x1, ld1, c1, part, grad_oihw, accumulate, B, H, W, 3,
+                                 stream);
 }
 
 // ---- 2x2-tap weight gradient (row a13) --------------------------------------------------------------------------
@@ -1133,7 +1174,7 @@ extern "C" int s2s_conv2x2_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8)) return S2S_ERR_SHAPE;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
   if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
-  WgradArgs a;
+  WgradArgs a{};
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
   a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
@@ -1179,7 +1220,7 @@ extern "C" int s2s_conv4x4s1_wgrad_nhwc(int dtype, const void* dy, int lddy, int
   if ((Cout % 8) || (cin % 8) || (lddy % 8) || (ldx % 8)) return S2S_ERR_SHAPE;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
   if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
-  WgradArgs a;
+  WgradArgs a{};
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
   a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;
@@ -1250,7 +1291,7 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
   if (x_plain && (H >= 16384 || W >= 16384)) return S2S_ERR_SHAPE;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return S2S_ERR_ALIGN;
   if ((long)B * (H + 1) * (W + 1) >= (1L << 31)) return S2S_ERR_SHAPE;
-  WgradArgs a;
+  WgradArgs a{};
   a.dy = dy; a.x0 = x; a.x1 = nullptr; a.part = part;
   a.lddy = lddy; a.Cout = Cout; a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0;
   a.B = B; a.H = H; a.W = W; a.lgc = 0; a.lgh = a.lgw = 0;

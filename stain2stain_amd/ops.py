@@ -176,7 +176,6 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     return out, stat
 
 
-@_timed("conv3x3_wgrad_mfma", _wgrad_flops)
 def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor], grad_oihw: torch.Tensor,
                   accumulate: bool = False) -> None:
     B, H, W, cout = dy.shape
@@ -194,6 +193,19 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
         raise RuntimeError("stain2stain_amd: conv3x3_wgrad gradient buffer has the wrong shape")
     s = _L().s2s_conv3x3_wgrad_splits(dt, B, H, W, c0 + c1, cout)
     part = _workspace(dy.device, s * 9 * cout * (c0 + c1), "wgrad")
+    if _PROFILE is not None and (_PROFILE_ONLY is None or "conv3x3_wgrad_mfma" in _PROFILE_ONLY):
+        # event-bracketed: the split MFMA kernel and the fold of its slabs as two launches, each timed on its own
+        # (rocprofv3 lists them as two kernels; the product path below issues them from one call)
+        for name, phase, work in (("conv3x3_wgrad_mfma", 1, _wgrad_flops(dy, x0, x1, grad_oihw)), ("wgrad_fold", 2, 0.0)):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = _L().s2s_conv3x3_wgrad_phase(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
+                                              int(accumulate), B, H, W, phase, _stream())
+            e1.record()
+            _native.check(rc, "conv3x3_wgrad")
+            _PROFILE.append((name, work, e0, e1))
+        return
     rc = _L().s2s_conv3x3_wgrad_nhwc(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
                                      int(accumulate), B, H, W, _stream())
     _native.check(rc, "conv3x3_wgrad")
