@@ -186,6 +186,8 @@ def main() -> None:
     ap.add_argument("--tile", type=int, default=TILE, help="tile edge (default 256; 512 = BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pix2pix", action="store_true", help="skip the second timed loop (the pix2pix G + D step)")
+    ap.add_argument("--sync-batchnorm", action="store_true",
+                    help="BatchNorm statistics over the global batch (configs/trainer/ddp.yaml:9; off in the stain experiments)")
     ap.add_argument("--sharded-optimizer", action="store_true",
                     help="gradient reduce-scatter + Adam on 1/world of every bucket + parameter all-gather instead of "
                          "all-reduce + full Adam (same results; ddp.GradBucketer mode 'reduce_scatter')")
@@ -287,7 +289,8 @@ def main() -> None:
         if use_dist:
             dist.destroy_process_group()
         return
-    trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5, sharded_optimizer=args.sharded_optimizer)
+    trainer = CFMTrainer(net, lr=1e-4, weight_decay=1e-5, sharded_optimizer=args.sharded_optimizer,
+                         sync_batchnorm=args.sync_batchnorm)
     g = torch.Generator().manual_seed(1984 + rank)
     B = args.batch
     # four distinct synthetic batches rotate through the loop (on one fixed batch the activations sparsify as training
@@ -403,6 +406,7 @@ def main() -> None:
                        "global_batch": B * world, "tile": TILE, "parallelism": f"dp{world}",
                        "final_loss": round(float(loss), 6), "loss_bits": float(loss).hex(),
                        "grad_exchange": (trainer.bucketer.mode if trainer.bucketer.enabled else "none"),
+                       "sync_batchnorm": trainer._sync_bn is not None,
                        "buckets_mb": [round((hi - lo) * 4 / 2 ** 20, 2) for _, lo, hi in trainer.bucketer.buckets]},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

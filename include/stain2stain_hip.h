@@ -126,6 +126,17 @@ int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldg
                     const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                     float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx, float* work, int B, int H,
                     int W, int C, void* stream);
+/* SyncBatchNorm (Lightning's sync_batchnorm: True, configs/trainer/ddp.yaml:9 = torch.nn.SyncBatchNorm): statistics
+ * over the GLOBAL batch.  Forward: s2s_bn_partial_sums folds the conv epilogue's partials into sums[2][C] (sum, sum of
+ * squares), the host all-reduces them and calls s2s_bn_finalize on them (nblk = 1, count = global element count).
+ * Backward: s2s_bn_relu_bwd_phase(phases = 1, count_total = global count) leaves (sum_dy, sum_dy_xhat) / count_total
+ * in work[4 nb C .. + 2 C), the host all-reduces those 2 C floats, phases = 2 applies; phases = 3 with the local
+ * count is s2s_bn_relu_bwd.  dgamma / dbeta stay rank-local sums (the gradient all-reduce averages them), as in torch. */
+int s2s_bn_partial_sums(const float* part, int nblk, int C, float* sums, void* stream);
+int s2s_bn_relu_bwd_phase(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
+                          const float* shift, const void* x, int ldx, const float* mean, const float* invstd,
+                          const float* gamma, float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx,
+                          int lddx, float* work, int B, int H, int W, int C, long count_total, int phases, void* stream);
 
 /* ---- bilinear x2, align_corners=True (+ F.pad to the skip size) (resample.hip) --------------------
  * nn.Upsample + F.pad of Up.forward (task_decoders.py:34,42-47); bias_nc (optional, float[B][C]) is added

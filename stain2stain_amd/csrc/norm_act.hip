@@ -113,6 +113,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// SyncBatchNorm (configs/trainer/ddp.yaml:9): the rank-local per-channel (sum, sum of squares) in exchange form,
+// sums[2][C]; the host all-reduces them over the ranks and hands them back to bn_finalize_kernel as a one-block partial
+// buffer with the global element count.
+template <int TPC>
+__global__ __launch_bounds__(256) void bn_partial_sums_kernel(const float* __restrict__ part, int nblk, int C,
+                                                              float* __restrict__ sums) {
+  const int c = blockIdx.x * (256 / TPC) + threadIdx.x / TPC, li = threadIdx.x % TPC;
+  if (c >= C) return;
+  double a, b;
+  channel_sums<TPC>(part, nblk, C, c, li, a, b);
+  if (li == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
+}
+
 __global__ void bn_eval_prepare_kernel(int C, const float* gamma, const float* beta, const float* rmean,
                                        const float* rvar, float eps, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,6 +602,17 @@ extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, c
   return S2S_OK;
 }
 
+extern "C" int s2s_bn_partial_sums(const float* part, int nblk, int C, float* sums, void* stream) {
+  if (!part || !sums) return S2S_ERR_NULL;
+  if (nblk <= 0 || C <= 0) return S2S_ERR_SHAPE;
+  if (finalize_tpc(nblk) == 256)
+    hipLaunchKernelGGL(bn_partial_sums_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums);
+  else
+    hipLaunchKernelGGL(bn_partial_sums_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 extern "C" int s2s_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* rmean,
                                    const float* rvar, float eps, float* scale, float* shift, void* stream) {
   if (!gamma || !beta || !rmean || !rvar || !scale || !shift) return S2S_ERR_NULL;
@@ -644,10 +668,15 @@ extern "C" int s2s_bn_bwd_blocks(int B, int H, int W, int C) {
 //   g1/gp : gradient wrt the ReLU output (dense or channel slice) / wrt the pooled output (may be null)
 //   scale/shift: the forward's folded BN affine (y = relu(x*scale+shift) is recomputed, not read); x: saved conv output;
 //   work: float[4*blocks*C + 2*C]
-extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
+// phases: 1 = reduction pass + per-channel finalize (dgamma, dbeta from the LOCAL sums; the two means c1, c2 = local
+// sums / count_total into work[4 nb C .. +2C)), 2 = the apply pass reading c1, c2 from there, 3 = both.  SyncBatchNorm
+// runs phase 1 with the GLOBAL element count, all-reduces the 2C floats over the ranks and runs phase 2: the same
+// exchange as torch.nn.SyncBatchNorm's backward (sum_dy, sum_dy_xmu), weight / bias gradients stay rank-local sums.
+extern "C" int s2s_bn_relu_bwd_phase(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
                                const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
                                float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx,
-                               float* work, int B, int H, int W, int C, void* stream) {
+                               float* work, int B, int H, int W, int C, long count_total, int phases, void* stream) {
+  if (phases < 1 || phases > 3 || count_total < (long)B * H * W) return S2S_ERR_SHAPE;
   if ((!g1 && !gp) || !scale || !shift || !x || !mean || !invstd || !gamma || !dgamma || !dbeta || !dx || !work) return S2S_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (lddx % 8) ||
       (g1 && (ldg1 % 8)) || (gp && (ldgp % 8)))
@@ -658,7 +687,7 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   float* part2 = work + (long)nb * 2 * C;   // [nb][C]
   float* c1 = part2 + (long)nb * 2 * C;     // [C]
   float* c2 = c1 + C;
-  const double count = (double)B * H * W;
+  const double count = (double)count_total;
   hipStream_t s = (hipStream_t)stream;
   // Gradient of the conv bias that feeds a train-mode BatchNorm: sum over pixels of dx, which the BN backward
   // formula makes identically zero (sum dz - N c1 - c2 sum xhat, with c1 = sum dz / N and sum xhat = 0).  The
@@ -671,20 +700,23 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
   static const int bn_rev = [] { const char* e = getenv("S2S_BN_REV"); return e ? atoi(e) : 1; }();
 #define S2S_BN_BWD(TT)                                                                                             \
-  if (gp) {                                                                                                        \
+  if (!(phases & 1)) {                                                                                             \
+  } else if (gp) {                                                                                                 \
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,   \
                        ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, part, B, H, W, C);                \
   } else {                                                                                                         \
     hipLaunchKernelGGL(bn_relu_bwd_reduce_flat_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1,             \
                        scale, shift, (const TT*)x, ldx, mean, invstd, part, (long)B * H * W, C);              \
   }                                                                                                                \
-  if (finalize_tpc(nb) == 256)                                                                                     \
+  if (!(phases & 1)) {                                                                                             \
+  } else if (finalize_tpc(nb) == 256)                                                                              \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<256>, dim3(C), dim3(256), 0, s, part, nb, C, count, dgamma, dbeta,   \
                        accumulate, c1, c2, dbias_zero);                                                            \
   else                                                                                                             \
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, s, part, nb, C, count, dgamma,  \
                        dbeta, accumulate, c1, c2, dbias_zero);                                                     \
-  if (gp) {                                                                                                        \
+  if (!(phases & 2)) {                                                                                             \
+  } else if (gp) {                                                                                                 \
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<TT>, grid, dim3(256), 0, s, (const TT*)g1, ldg1, (const TT*)gp,    \
                        ldgp, scale, shift, (const TT*)x, ldx, mean, invstd, gamma, c1, c2, (TT*)dx, lddx,     \
                        dbias_conv ? part2 : nullptr, B, H, W, C);                                                  \
@@ -697,9 +729,17 @@ extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* 
   else if (dtype == S2S_F32) { S2S_BN_BWD(float) }
   else return S2S_ERR_DTYPE;
 #undef S2S_BN_BWD
-  if (dbias_conv)
+  if (dbias_conv && (phases & 2))
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, part2, prereduce(part2, nb, C, s),
                        C, dbias_conv, accumulate);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+extern "C" int s2s_bn_relu_bwd(int dtype, const void* g1, int ldg1, const void* gp, int ldgp, const float* scale,
+                               const float* shift, const void* x, int ldx, const float* mean, const float* invstd, const float* gamma,
+                               float* dgamma, float* dbeta, float* dbias_conv, int accumulate, void* dx, int lddx,
+                               float* work, int B, int H, int W, int C, void* stream) {
+  return s2s_bn_relu_bwd_phase(dtype, g1, ldg1, gp, ldgp, scale, shift, x, ldx, mean, invstd, gamma, dgamma, dbeta,
+                               dbias_conv, accumulate, dx, lddx, work, B, H, W, C, (long)B * H * W, 3, stream);
 }

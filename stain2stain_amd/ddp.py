@@ -146,10 +146,13 @@ class GradBucketer:
             if self._native_rs:
                 works.append(dist.all_gather_into_tensor(flat_param[lo:hi], flat_param[slo:shi], group=self.pg,
                                                          async_op=True))
-            else:       # gloo: list form
+            else:       # gloo: list form, on host copies when the parameters live on a GPU (tests only)
                 n = shi - slo
-                outs = [flat_param[lo + r * n: lo + (r + 1) * n] for r in range(self.world)]
-                works.append(dist.all_gather(outs, flat_param[slo:shi].clone(), group=self.pg, async_op=True))
+                mine = flat_param[slo:shi].detach().cpu().clone()
+                outs = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(outs, mine, group=self.pg)
+                for r, o in enumerate(outs):
+                    flat_param[lo + r * n: lo + (r + 1) * n].copy_(o)
         for w in works:
             w.wait()
 

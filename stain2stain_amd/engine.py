@@ -20,12 +20,55 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import contextlib
+
 import torch
+import torch.distributed as dist
 
 from . import ops
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------
+# SyncBatchNorm
+# ------------------------------------------------------------------------------------------------
+class SyncBNExchange:
+    """The two exchanges of ``torch.nn.SyncBatchNorm`` (what Lightning's ``sync_batchnorm: True`` of the reference's
+    ``trainer=ddp`` preset, configs/trainer/ddp.yaml:9, wraps every BatchNorm2d in): the per-channel (sum, sum of squares)
+    of the forward and (sum dy, sum dy * xhat) / N of the backward, summed over the ranks of ``process_group``.  Each is
+    one small blocking all-reduce (2 C floats) per layer, in stream order on RCCL; with a ``gloo`` group the 2 C floats
+    are staged through the host.  Every rank must hold the same number of elements per channel."""
+
+    def __init__(self, process_group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("stain2stain_amd: SyncBatchNorm needs an initialised torch.distributed process group")
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self._host = dist.get_backend(process_group) != "nccl"
+
+    def __call__(self, t: torch.Tensor) -> None:
+        if self._host and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+
+sync_bn: Optional[SyncBNExchange] = None      # set for the duration of a training step (sync_batchnorm below)
+
+
+@contextlib.contextmanager
+def sync_batchnorm(exchange: Optional[SyncBNExchange]):
+    """Train-mode BatchNorm layers run inside this context take their statistics over all ranks of ``exchange``."""
+    global sync_bn
+    prev, sync_bn = sync_bn, exchange
+    try:
+        yield
+    finally:
+        sync_bn = prev
 
 
 # ------------------------------------------------------------------------------------------------
@@ -106,6 +149,7 @@ class LayerCtx:
     raw: torch.Tensor                   # conv output
     act: torch.Tensor                   # ReLU output
     stats: torch.Tensor                 # [4, C]: mean, invstd, scale, shift
+    count: Optional[int] = None         # elements per channel the statistics were taken over (None = the local B*H*W)
 
 
 @dataclass
@@ -140,6 +184,12 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         else:
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
         count = raw.shape[0] * raw.shape[1] * raw.shape[2]
+        sx = sync_bn
+        if sx is not None:      # statistics over the global batch: all-reduce the per-channel sums, finalize on those
+            sums = ops.bn_partial_sums(stat)
+            sx(sums)
+            stat = sums.view(2, -1, 1)
+            count *= sx.world
         if count <= 1:      # torch.nn.functional.batch_norm raises the same way in training mode
             raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                              f"{[raw.shape[0], raw.shape[3], raw.shape[1], raw.shape[2]]}")
@@ -150,7 +200,7 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
                              bn.num_batches_tracked if track else None,
                              BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps)
         act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
-        return LayerCtx(x0, x1, raw, act, st), act, pooled
+        return LayerCtx(x0, x1, raw, act, st, count if sx is not None else None), act, pooled
     ss = cb.eval_affine()
     if stem:
         raw, _ = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=False)
@@ -211,7 +261,8 @@ def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool,
     dgamma = _g(grads, f"{p}.{i_bn}.weight")
     dbeta = _g(grads, f"{p}.{i_bn}.bias")
     dbias = _g(grads, f"{p}.{i_conv}.bias") if cb.conv.bias is not None else None
-    draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate)
+    draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate,
+                           exchange=sync_bn if lc.count is not None else None, count_total=lc.count)
     dw = _g(grads, f"{p}.{i_conv}.weight")
     if stem:
         run_on_side(lambda: ops.stem_wgrad(draw, lc.x0, dw, None, accumulate), (draw,))

@@ -307,6 +307,15 @@ def bn_finalize(stat: torch.Tensor, count: int, gamma, beta, running_mean, runni
     return out
 
 
+def bn_partial_sums(stat: torch.Tensor) -> torch.Tensor:
+    """Rank-local per-channel (sum, sum of squares) [2, C] of a conv epilogue's partial buffer: what SyncBatchNorm
+    all-reduces; ``bn_finalize(sums.view(2, C, 1), global_count, ...)`` finishes the statistics."""
+    _, C, nblk = stat.shape
+    sums = torch.empty((2, C), dtype=torch.float32, device=stat.device)
+    _native.check(_L().s2s_bn_partial_sums(_f32(stat), nblk, C, _f32(sums), _stream()), "bn_partial_sums")
+    return sums
+
+
 def bn_eval_prepare(gamma, beta, rmean, rvar, eps: float = 1e-5):
     C = gamma.numel()
     out = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
@@ -347,9 +356,12 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
 @_timed("bn_relu_bwd")
 def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], x: torch.Tensor,
                 stats: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
-                dbias_conv: Optional[torch.Tensor], accumulate: bool = False) -> torch.Tensor:
+                dbias_conv: Optional[torch.Tensor], accumulate: bool = False, exchange=None,
+                count_total: Optional[int] = None) -> torch.Tensor:
     """Returns dx (gradient wrt the conv output x).  stats = bn_finalize() output (rows mean, invstd, scale,
-    shift); the ReLU mask / pool winner are recomputed from x with the forward's scale and shift."""
+    shift); the ReLU mask / pool winner are recomputed from x with the forward's scale and shift.
+    SyncBatchNorm: ``exchange(t)`` all-reduces (sum) the [2C] tensor of per-channel means between the reduction and the
+    apply pass, ``count_total`` is the global element count they are taken over."""
     B, H, W, C = x.shape
     px, ldx = _nhwc(x)
     p1, ld1 = (0, 8) if g1 is None else _nhwc(g1)
@@ -357,6 +369,17 @@ def bn_relu_bwd(g1: Optional[torch.Tensor], gp: Optional[torch.Tensor], x: torch
     dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     nb = _L().s2s_bn_bwd_blocks(B, H, W, C)
     work = torch.empty((4 * nb * C + 2 * C,), dtype=torch.float32, device=x.device)
+    if exchange is not None:
+        for phase in (1, 2):
+            rc = _L().s2s_bn_relu_bwd_phase(_dt(x), p1, ld1, p2, ld2, stats[2].data_ptr(), stats[3].data_ptr(), px, ldx,
+                                            stats[0].data_ptr(), stats[1].data_ptr(),
+                                            _f32(gamma), _f32(dgamma), _f32(dbeta), _f32(dbias_conv), int(accumulate),
+                                            dx.data_ptr(), C, _f32(work), B, H, W, C,
+                                            int(count_total if count_total is not None else B * H * W), phase, _stream())
+            _native.check(rc, "bn_relu_bwd")
+            if phase == 1:
+                exchange(work[4 * nb * C:])
+        return dx
     rc = _L().s2s_bn_relu_bwd(_dt(x), p1, ld1, p2, ld2, stats[2].data_ptr(), stats[3].data_ptr(), px, ldx,
                               stats[0].data_ptr(), stats[1].data_ptr(),
                               _f32(gamma), _f32(dgamma), _f32(dbeta), _f32(dbias_conv), int(accumulate),

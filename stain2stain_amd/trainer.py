@@ -92,10 +92,12 @@ class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
                  bucket_mb: float = 4.0, process_group=None, sync_loss: bool = True, max_bucket_mb: float = 16.0,
-                 sharded_optimizer: bool = False):
+                 sharded_optimizer: bool = False, sync_batchnorm: bool = False):
         """``sharded_optimizer``: exchange gradients by reduce-scatter, run the fused Adam on this rank's 1/world of every
         bucket and all-gather the updated parameters (ddp.GradBucketer, mode "reduce_scatter") instead of all-reduce +
-        a full Adam pass on every rank.  Same results, same wire volume, 1/world of the optimiser's HBM traffic."""
+        a full Adam pass on every rank.  Same results, same wire volume, 1/world of the optimiser's HBM traffic.
+        ``sync_batchnorm``: BatchNorm statistics over the global batch (Lightning's ``sync_batchnorm: True``,
+        configs/trainer/ddp.yaml:9; the stain experiments leave it off): two 2C-float all-reduces per layer and step."""
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: CFMTrainer needs the network on a GPU (HIP-only implementation)")
@@ -136,6 +138,7 @@ class CFMTrainer:
         self.bucketer = GradBucketer(self.flat_g, sizes, bucket_mb, process_group, max_bucket_mb,
                                      "reduce_scatter" if sharded_optimizer else "allreduce")
         self._group = 0
+        self._sync_bn = engine.SyncBNExchange(process_group) if sync_batchnorm and self.bucketer.enabled else None
         broadcast_from_rank0([self.flat_p] + [b for b in net.buffers()], process_group)
         self._blocks = list(net.encoder._blocks) + list(net.flow_decoder.up_blocks)
         # one launch re-packs every MFMA conv's weights (all but the stem, which reads the fp32 master directly)
@@ -179,10 +182,11 @@ class CFMTrainer:
         t = t.float().contiguous()
         eps_noise = torch.randn_like(x0) if self.sigma != 0.0 else None
         xt, ut = ops.cfm_sample(x0, x1, t, self.sigma, eps_noise)
-        ectx = engine.encoder_forward(enc._blocks, xt, dt, True)
-        temb = ops.time_embedding(t, net.time_embedding.dim)
-        feats = ectx.feats
-        dctx = engine.decoder_forward(dec, feats[-1], feats[:-1][::-1], temb, dt, True, with_head=False)
+        with engine.sync_batchnorm(self._sync_bn):
+            ectx = engine.encoder_forward(enc._blocks, xt, dt, True)
+            temb = ops.time_embedding(t, net.time_embedding.dim)
+            feats = ectx.feats
+            dctx = engine.decoder_forward(dec, feats[-1], feats[:-1][::-1], temb, dt, True, with_head=False)
         # head conv + loss + their backward in one sweep over the last activation
         loss, g_head, v = ops.head_loss_fused(dctx.lows[-1], dec.outc.weight.detach(),
                                               dec.outc.bias.detach() if dec.outc.bias is not None else None, ut,
@@ -193,11 +197,12 @@ class CFMTrainer:
         self._group = 0
         engine.side_stream = self._side if self.overlap_wgrad else None
         try:
-            dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
-                                                       on_group_done=self._group_done)
-            L = len(feats) - 1
-            dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
-            engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
+            with engine.sync_batchnorm(self._sync_bn):
+                dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
+                                                           on_group_done=self._group_done)
+                L = len(feats) - 1
+                dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
+                engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
         finally:
             engine.side_stream = None
         if self._side is not None:          # whatever reads the gradients next (Adam, a test) is on the compute stream

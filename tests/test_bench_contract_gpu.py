@@ -68,3 +68,9 @@ def test_rccl_path_in_a_fresh_process_matches_the_single_process_run():
         assert other["config"]["loss_bits"] == plain["config"]["loss_bits"]
         assert other["pix2pix"]["config"]["loss_bits"] == plain["pix2pix"]["config"]["loss_bits"]
     assert ddp["pix2pix"]["config"]["grad_exchange"] == "allreduce" and max(ddp["pix2pix"]["config"]["buckets_mb"]) <= 16.0
+    # SyncBatchNorm's small all-reduces on RCCL (two per layer and step): at world size 1 they are identities, the
+    # statistics go through the exchange form (float sums, one-block finalize), so the loss agrees to rounding
+    syn = _run("--no-cpu-baseline", "--no-pix2pix", "--sync-batchnorm", steps=3,
+               env={"S2S_FORCE_DDP": "1", "MASTER_PORT": "29613", **port})
+    assert syn["config"]["sync_batchnorm"] is True and plain["config"]["sync_batchnorm"] is False
+    assert abs(syn["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-3 * plain["config"]["final_loss"]
