@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from conftest import relerr
 
 pytestmark = pytest.mark.gpu
+YARD_FACTOR = 4.0     # full-size gradients: allowed multiple of the oracle's own fp32-vs-fp64 L2 deviation (measured <= 2.1)
 DEV = "cuda"
 BF = torch.bfloat16
 B = 16
@@ -153,9 +154,10 @@ def test_headline_gradients_fp32_mode_against_the_oracle():
     knife edge, so two correct fp32 evaluations differ - the oracle's own fp32 gradients against its fp64 ones deviate
     by up to 2.7e-2 (max-norm, per tensor) at this size, this path by up to 6.4e-2 against either
     (profiles/r01_prod_grad_parity_B4_256.txt).  Decision-free parts are exact: the head and the last BatchNorm'd conv
-    agree to < 1e-4 (measured 2e-7 .. 3e-5), the rest of the last decoder level to 5e-3 (measured 1.2e-3); everything
-    else is bounded at 0.2.  The 1e-3 gradient criterion proper is checked on the screened golden fixtures
-    (test_e2e_gpu.py)."""
+    agree to < 1e-4 (measured 2e-7 .. 3e-5), the rest of the last decoder level to 5e-3 (measured 1.2e-3).  Every other
+    tensor is held against the oracle run in fp64: its L2 distance from those gradients may be at most YARD_FACTOR times
+    the distance of the oracle's own fp32 gradients from them (round 1 accepted 0.2 in max-norm here, which a wrong kernel
+    could have passed).  The 1e-3 gradient criterion proper is checked on the screened golden fixtures (test_e2e_gpu.py)."""
     import os
     from oracle import unet_oracle as O
     from stain2stain_amd import CFMTrainer, FlowUNet
@@ -178,18 +180,35 @@ def test_headline_gradients_fp32_mode_against_the_oracle():
     finally:
         torch.set_num_threads(threads)
     assert relerr(v.float().cpu(), v_ref) < 1e-3 and abs(float(loss) - float(l_ref)) < 1e-5 * abs(float(l_ref))
+    # the yardstick for everything that is not decision-free: the oracle evaluated in fp64 on the same inputs.  How far
+    # the oracle's OWN fp32 gradients are from it (L2 per tensor) is what flipped knife-edge decisions cost at this
+    # size; this path has to stay within a small multiple of that, measured against the same fp64 gradients.
+    P64 = {k: (p.double() if p.is_floating_point() else p) for k, p in P.items()}
+    te = O.time_embedding
+    O.time_embedding = lambda tt, d: te(tt.float(), d).double()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    try:
+        _, _, ref64, _ = O.loss_and_grads(P64, x0.double(), x1.double(), t.double())
+    finally:
+        O.time_embedding = te
+        torch.set_num_threads(threads)
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())
     gscale = max(float(r.abs().max()) for r in ref.values())
+    report = []
     for k, r in ref.items():
         if float(r.abs().max()) < 1e-3 * gscale:
             continue                      # e.g. conv biases ahead of BatchNorm: exactly 0 here, rounding noise there
         e = relerr(got[k], r)
         if k.startswith(("flow_decoder.outc", "flow_decoder.ups.3.conv.double_conv.4")):
-            bound = 1e-4
+            assert e < 1e-4, (k, e)
         elif k.startswith("flow_decoder.ups.3"):
-            bound = 5e-3
-        else:
-            bound = 0.2
-        assert e < bound, (k, e)
+            assert e < 5e-3, (k, e)
+        yard, mine = l2(r, ref64[k]), l2(got[k], ref64[k])
+        report.append((mine / max(yard, 1e-12), mine, yard, k))
+        assert mine <= max(YARD_FACTOR * yard, 2e-3), (k, mine, yard)
+    if os.environ.get("S2S_TEST_REPORT"):
+        for row in sorted(report, reverse=True)[:12]:
+            print("ratio %.2f  hip-vs-fp64 %.3e  oracle32-vs-fp64 %.3e  %s" % row)
 
 
 def test_headline_sampling_path_matches_the_oracle_fp32():
