@@ -15,6 +15,7 @@ Weak scaling: every rank steps its own 16 tiles; the only collective is the grad
 One JSON line on rank 0; see README / DESIGN.md for the roofline and cpu_baseline objects.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -99,6 +100,24 @@ def pix2pix_flops(batch: int, tile: int, ngf: int = 64, ndf: int = 64, num_downs
             "g_fwd_per_tile": g_fwd, "d_fwd_per_tile": d_fwd}
 
 
+class _GcPause:
+    """No cyclic garbage collection inside a timed region.  A full (generation 2) collection walks every object torch
+    has created -- 60-80 ms here -- and when it fires is a matter of allocation counts: with the package loaded from its
+    bytecode cache it fell into the 20 timed steps of the driver's run (+3.2 ms per step: 1440 instead of 2030 tiles/s),
+    with the package compiled from source it fell into the warm-up.  Reference counting frees the step's tensors either
+    way; training loops that care do the same (gc.freeze() after set-up)."""
+
+    def __init__(self):
+        self.was = gc.isenabled() and os.environ.get("S2S_BENCH_GC") != "1"
+        if self.was:
+            gc.collect()
+            gc.disable()
+
+    def resume(self) -> None:
+        if self.was:
+            gc.enable()
+
+
 def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     """BASELINE.json configs[1] as literally worded: 8-level U-Net generator + 70x70 PatchGAN discriminator, batch 16 per
     GPU, bf16, GAN(BCE) + 100 L1, two Adam(2e-4, 0.5/0.999) -- the fused HIP engine (stain2stain_amd.Pix2PixTrainer),
@@ -117,6 +136,7 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     steps, warmup = args.steps, args.warmup
     for i in range(warmup):
         tr.step(*data[i % 4])
+    gc_pause = _GcPause()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -140,6 +160,7 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc_pause.resume()
     if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -215,6 +236,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if os.environ.get("S2S_BENCH_OWN_STREAM") == "1":
+        # everything on a non-blocking stream of our own instead of the legacy default stream (experiments with
+        # S2S_WGRAD_CUS: a CU-masked stream is a blocking stream, which synchronises implicitly with the default one)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     use_dist = world > 1 or os.environ.get("S2S_FORCE_DDP") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -241,6 +266,7 @@ def main() -> None:
         net.eval()
         for _ in range(max(1, args.warmup // 3)):
             euler_generate(net, src, args.euler_steps, graph=args.graph)
+        gc_pause = _GcPause()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -260,6 +286,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc_pause.resume()
         if use_dist:
             el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -333,6 +360,7 @@ def main() -> None:
     for i in range(args.warmup):
         x0, x1 = feed(i) if feed else pool[i % 4]
         trainer.step(x0, x1, ts[i])
+    gc_pause = _GcPause()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -346,6 +374,7 @@ def main() -> None:
     prof, timed_steps = [], 0
     t0 = time.perf_counter()
     loss = None
+    ms0 = dict(torch.cuda.memory_stats(dev)) if os.environ.get("S2S_BENCH_MEMSTAT") else None
     for i in range(args.steps):
         x0, x1 = feed(args.warmup + i) if feed else pool[(args.warmup + i) % 4]
         sampled = i % every == 0
@@ -363,6 +392,12 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc_pause.resume()
+    if ms0 is not None:
+        ms1 = torch.cuda.memory_stats(dev)
+        keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.current",
+                "reserved_bytes.all.peak", "allocated_bytes.all.peak", "segment.all.current", "allocation.all.allocated")
+        print("memstat", {k: (ms0.get(k), ms1.get(k)) for k in keys}, file=sys.stderr)
     if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)

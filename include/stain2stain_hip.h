@@ -365,6 +365,13 @@ int s2s_p2p_act_bwd_blocks(long npix, int C);
 int s2s_p2p_act_bwd(int dtype, const void* g, int ldg, const void* g2, int ldg2, const void* a, int lda, float slope,
                     void* dz, int lddz, float* work, float* dbias, int accumulate, long npix, int C, void* stream);
 
+/* ---- streams (runtime.hip) -------------------------------------------------------------------------
+ * A HIP stream confined to the compute units whose bits are set in mask_words (bit i of word i/32 = CU i, as
+ * hipExtStreamCreateWithCUMask numbers them); *out_stream receives the hipStream_t.  Used for the weight-gradient side
+ * stream of the fused trainers; any hipStream_t may be passed as `stream` to every entry point above. */
+int s2s_stream_create_cu_mask(const unsigned* mask_words, int n_words, long* out_stream);
+int s2s_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

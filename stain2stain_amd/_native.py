@@ -16,7 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libstain2stain_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "stain2stain_hip.h")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wgrad_mfma.hip", "conv_edge.hip", "norm_act.hip", "resample.hip",
-           "flow.hip", "optim.hip", "input_pipeline.hip", "seg_loss.hip", "loss_variants.hip", "instnorm.hip", "pix2pix.hip"]
+           "flow.hip", "optim.hip", "input_pipeline.hip", "seg_loss.hip", "loss_variants.hip", "instnorm.hip", "pix2pix.hip",
+           "runtime.hip"]
 
 _lib: Optional[ctypes.CDLL] = None
 

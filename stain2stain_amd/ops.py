@@ -100,6 +100,37 @@ def profile_start(only=None) -> None:
     _PROFILE_ONLY = set(only) if only else None
 
 
+def cu_masked_stream(device, spec: str) -> torch.cuda.Stream:
+    """A HIP stream confined to a subset of the compute units: ``spec`` = "K:M" enables CU i iff i % M < K (e.g. "3:4" =
+    three quarters of the chip, spread evenly whatever the CU numbering).  For the weight-gradient side stream."""
+    import ctypes
+    k, m = (int(v) for v in spec.split(":"))
+    if not 0 < k <= m:
+        raise ValueError("CU mask spec K:M needs 0 < K <= M")
+    dev = torch.device(device)
+    n = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (ctypes.c_uint32 * ((n + 31) // 32))()
+    for i in range(n):
+        if i % m < k:
+            words[i // 32] |= 1 << (i % 32)
+    out = ctypes.c_long(0)
+    with torch.cuda.device(dev):
+        _native.check(_L().s2s_stream_create_cu_mask(ctypes.addressof(words), len(words), ctypes.addressof(out)),
+                      "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+def side_stream_for(device) -> Optional[torch.cuda.Stream]:
+    """The trainers' weight-gradient stream: None with S2S_WGRAD_STREAM=0, CU-masked with S2S_WGRAD_CUS=K:M."""
+    import os
+    if os.environ.get("S2S_WGRAD_STREAM", "1") == "0":
+        return None
+    spec = os.environ.get("S2S_WGRAD_CUS", "")
+    if spec and spec != "0":
+        return cu_masked_stream(device, spec)
+    return torch.cuda.Stream(device=device)
+
+
 def profile_stop() -> list:
     """[(op name, algorithmic work, start event, end event)] recorded since profile_start()."""
     global _PROFILE

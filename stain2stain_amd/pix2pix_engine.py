@@ -228,7 +228,7 @@ class Pix2PixTrainer:
         self.in_channels, self.out_channels = G.in_channels, G.out_channels
         # weight gradients overlap the bandwidth-bound backward passes on a second HIP stream (engine.run_on_side);
         # S2S_WGRAD_STREAM=0 keeps everything on one stream, overlap_wgrad = False does so for a single step
-        self._side = torch.cuda.Stream(device=dev) if os.environ.get("S2S_WGRAD_STREAM", "1") != "0" else None
+        self._side = ops.side_stream_for(dev)
         self.overlap_wgrad = True
         self.last: Dict[str, torch.Tensor] = {}
 

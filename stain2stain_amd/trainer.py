@@ -151,7 +151,7 @@ class CFMTrainer:
             start += ((cb.cout + 31) // 32) * ((cb.cin + 31) // 32)
         # weight gradients overlap the bandwidth-bound backward passes on a second HIP stream (engine.run_on_side);
         # S2S_WGRAD_STREAM=0 keeps everything on one stream
-        self._side = torch.cuda.Stream(device=dev) if os.environ.get("S2S_WGRAD_STREAM", "1") != "0" else None
+        self._side = ops.side_stream_for(dev)
         self.overlap_wgrad = True       # bench.py clears it on the steps whose kernels it brackets with HIP events
         self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._pack_total = start
@@ -205,8 +205,7 @@ class CFMTrainer:
                 engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
         finally:
             engine.side_stream = None
-        if self._side is not None:          # whatever reads the gradients next (Adam, a test) is on the compute stream
-            torch.cuda.current_stream().wait_stream(self._side)
+        engine.join_side(self._side)        # whatever reads the gradients next (Adam, a test) is on the compute stream
         return loss, dctx.v
 
     def _group_done(self) -> None:
@@ -221,8 +220,7 @@ class CFMTrainer:
         self._group += 1
 
     def optimizer_step(self) -> None:
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)     # the weight gradients
+        engine.join_side(self._side)        # the weight gradients
         self.bucketer.wait_all()
         self.step_count += 1
         for lo, hi in self.bucketer.shards():          # everything, or this rank's slices in sharded mode
