@@ -234,6 +234,7 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local %= max(1, torch.cuda.device_count())      # more ranks than GPUs (rehearsals on a one-GPU box): share devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if os.environ.get("S2S_BENCH_OWN_STREAM") == "1":
@@ -244,7 +245,11 @@ def main() -> None:
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("S2S_BENCH_BACKEND", "nccl")       # "gloo": rehearse N ranks on fewer GPUs (RCCL wants
+        if backend == "nccl":                                       # one device per rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from stain2stain_amd import CFMTrainer, FlowUNet, euler_generate, ops
 

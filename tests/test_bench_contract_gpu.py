@@ -74,3 +74,22 @@ def test_rccl_path_in_a_fresh_process_matches_the_single_process_run():
                env={"S2S_FORCE_DDP": "1", "MASTER_PORT": "29613", **port})
     assert syn["config"]["sync_batchnorm"] is True and plain["config"]["sync_batchnorm"] is False
     assert abs(syn["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-3 * plain["config"]["final_loss"]
+
+
+def test_two_rank_launch_as_the_driver_does_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` (the driver's multi-GPU command) on the
+    one-GPU test box: both ranks share the device and the transport is gloo (S2S_BENCH_BACKEND; RCCL wants a device per
+    rank), everything else -- env rendezvous, per-rank shards, barriers, max-over-ranks clock, rank 0's single JSON line,
+    the bucketed gradient exchange behind the HIP backward -- is the code the 8-GPU run takes."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pix2pix"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={**os.environ, "S2S_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and d["config"]["grad_exchange"] == "allreduce" and "cpu_baseline" not in d
+    assert abs(d["value"] - 32 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"] and d["config"]["final_loss"] > 0
