@@ -59,8 +59,8 @@ def _cfm_steps(trainer, net, x0, x1, t, steps=2):
         if s == 0:
             trainer.bucketer.wait_all()
             torch.cuda.synchronize()
-            out["grad"] = (trainer.flat_g * trainer.bucketer.grad_scale).cpu()
-            trainer.bucketer._works = []          # exchanged already; optimizer_step's wait_all has nothing left to join
+            out["grad"] = (trainer.flat_g * trainer.bucketer.grad_scale).cpu()     # (optimizer_step's own wait_all then
+                                                                                   # finds nothing left to join)
         trainer.optimizer_step()
         out["loss"].append(float(loss))
     torch.cuda.synchronize()
