@@ -117,7 +117,10 @@ def cu_masked_stream(device, spec: str) -> torch.cuda.Stream:
     with torch.cuda.device(dev):
         _native.check(_L().s2s_stream_create_cu_mask(ctypes.addressof(words), len(words), ctypes.addressof(out)),
                       "stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=dev)
+    stream = torch.cuda.ExternalStream(out.value, device=dev)
+    import weakref
+    weakref.finalize(stream, _L().s2s_stream_destroy, out.value)        # ExternalStream does not own the hipStream_t
+    return stream
 
 
 def side_stream_for(device) -> Optional[torch.cuda.Stream]:

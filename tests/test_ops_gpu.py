@@ -343,3 +343,23 @@ def test_head_loss_fused_matches_separate_ops(dtype, C):
     assert relerr(nchw(dx), a.grad) < tol_act(dtype)
     assert relerr(dw.cpu(), w.grad) < (5e-3 if C == 24 else 1e-4)   # the per-pixel form stages a bf16 copy for dW
     assert relerr(db.cpu(), b.grad) < 1e-4
+
+
+def test_cu_masked_stream_runs_kernels():
+    """s2s_stream_create_cu_mask: a stream confined to three quarters of the CUs runs a conv launch to the same bits as
+    the default stream (engine.run_on_side's stream when S2S_WGRAD_CUS is set); bad specs are refused."""
+    from stain2stain_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.rand(2, 32, 32, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    w = (torch.rand(64, 64, 3, 3, device="cuda", generator=g) - 0.5) * 0.1
+    wf, _ = ops.pack_conv3x3(w, torch.bfloat16)
+    ref, _ = ops.conv3x3(x, None, wf, None, 64)
+    side = ops.cu_masked_stream("cuda:0", "3:4")
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got, _ = ops.conv3x3(x, None, wf, None, 64)
+    side.synchronize()
+    assert torch.equal(got, ref)
+    for bad in ("0:4", "5:4"):
+        with pytest.raises(ValueError):
+            ops.cu_masked_stream("cuda:0", bad)
