@@ -119,7 +119,8 @@ def cu_masked_stream(device, spec: str) -> torch.cuda.Stream:
                       "stream_create_cu_mask")
     stream = torch.cuda.ExternalStream(out.value, device=dev)
     import weakref
-    weakref.finalize(stream, _L().s2s_stream_destroy, out.value)        # ExternalStream does not own the hipStream_t
+    fin = weakref.finalize(stream, _L().s2s_stream_destroy, out.value)  # ExternalStream does not own the hipStream_t
+    fin.atexit = False            # not at interpreter exit: the HIP runtime may be gone by then (process teardown frees it)
     return stream
 
 
