@@ -147,7 +147,7 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     t0 = time.perf_counter()
     losses = None
     for i in range(steps):
-        sampled = i % every == 0
+        sampled = i % every == min(every // 2, steps - 1)    # mid-cycle: not the first step after the warm-up barrier
         tr.overlap_wgrad = not sampled          # bracketed steps on one stream (see the note in the CFM loop)
         if sampled:
             ops.profile_start(None if args.breakdown else convs)
@@ -279,7 +279,7 @@ def main() -> None:
         prof, timed_steps = [], 0
         t0 = time.perf_counter()
         for i in range(args.steps):
-            sampled = i % max(1, args.event_every) == 0 and not args.graph     # (no event brackets inside a graph)
+            sampled = i % max(1, args.event_every) == min(max(1, args.event_every) // 2, args.steps - 1) and not args.graph     # (no event brackets inside a graph)
             if sampled:
                 ops.profile_start(("conv3x3_mfma",))
             out = euler_generate(net, src, args.euler_steps, graph=args.graph)
@@ -382,7 +382,7 @@ def main() -> None:
     ms0 = dict(torch.cuda.memory_stats(dev)) if os.environ.get("S2S_BENCH_MEMSTAT") else None
     for i in range(args.steps):
         x0, x1 = feed(args.warmup + i) if feed else pool[(args.warmup + i) % 4]
-        sampled = i % every == 0
+        sampled = i % every == min(every // 2, args.steps - 1)    # mid-cycle: not the first step after the warm-up barrier
         # the bracketed steps run on ONE stream, so that an event pair times its kernel alone; all other steps overlap
         # the weight gradients with the bandwidth-bound backward passes on a side stream (engine.run_on_side)
         trainer.overlap_wgrad = not sampled
