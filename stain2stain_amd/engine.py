@@ -62,7 +62,8 @@ sync_bn: Optional[SyncBNExchange] = None      # set for the duration of a traini
 
 @contextlib.contextmanager
 def sync_batchnorm(exchange: Optional[SyncBNExchange]):
-    """Train-mode BatchNorm layers run inside this context take their statistics over all ranks of ``exchange``."""
+    """Train-mode BatchNorm layers whose FORWARD runs inside this context take their statistics over all ranks of
+    ``exchange``; the layer remembers the exchange, so its backward (autograd's, whenever it runs) uses the same one."""
     global sync_bn
     prev, sync_bn = sync_bn, exchange
     try:
@@ -150,6 +151,7 @@ class LayerCtx:
     act: torch.Tensor                   # ReLU output
     stats: torch.Tensor                 # [4, C]: mean, invstd, scale, shift
     count: Optional[int] = None         # elements per channel the statistics were taken over (None = the local B*H*W)
+    sync: Optional["SyncBNExchange"] = None     # SyncBatchNorm: the exchange the forward used (its backward uses it too)
 
 
 @dataclass
@@ -200,7 +202,7 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
                              bn.num_batches_tracked if track else None,
                              BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps)
         act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
-        return LayerCtx(x0, x1, raw, act, st, count if sx is not None else None), act, pooled
+        return LayerCtx(x0, x1, raw, act, st, count if sx is not None else None, sx), act, pooled
     ss = cb.eval_affine()
     if stem:
         raw, _ = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=False)
@@ -270,7 +272,7 @@ def _conv_bn_relu_bwd(cb: ConvBN, lc: LayerCtx, g1, gp, grads, accumulate: bool,
     dbeta = _g(grads, f"{p}.{i_bn}.bias")
     dbias = _g(grads, f"{p}.{i_conv}.bias") if cb.conv.bias is not None else None
     draw = ops.bn_relu_bwd(g1, gp, lc.raw, lc.stats, cb.bn.weight.detach(), dgamma, dbeta, dbias, accumulate,
-                           exchange=sync_bn if lc.count is not None else None, count_total=lc.count)
+                           exchange=lc.sync, count_total=lc.count)
     dw = _g(grads, f"{p}.{i_conv}.weight")
     if stem:
         run_on_side(lambda: ops.stem_wgrad(draw, lc.x0, dw, None, accumulate), (draw,))

@@ -197,12 +197,11 @@ class CFMTrainer:
         self._group = 0
         engine.side_stream = self._side if self.overlap_wgrad else None
         try:
-            with engine.sync_batchnorm(self._sync_bn):
-                dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
-                                                           on_group_done=self._group_done)
-                L = len(feats) - 1
-                dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
-                engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
+            dbott, dskips, _ = engine.decoder_backward(dec, dctx, None, self.grads_dec, g_head=g_head,
+                                                       on_group_done=self._group_done)
+            L = len(feats) - 1
+            dfeats = [dskips[L - 1 - l] for l in range(L)] + [dbott]
+            engine.encoder_backward(enc._blocks, ectx, dfeats, self.grads_enc, on_group_done=self._group_done)
         finally:
             engine.side_stream = None
         engine.join_side(self._side)        # whatever reads the gradients next (Adam, a test) is on the compute stream
