@@ -55,7 +55,7 @@ def _double_conv_container(cin: int, cout: int) -> nn.Module:
 def _bundles(holder: nn.Module, prefix: str) -> Tuple[engine.ConvBN, engine.ConvBN]:
     seq = holder.double_conv
     p = f"{prefix}.double_conv"
-    return engine.ConvBN(p, "0", "1", seq[0], seq[1]), engine.ConvBN(p, "3", "4", seq[3], seq[4])
+    return engine.ConvBN(p, "0", "1", seq), engine.ConvBN(p, "3", "4", seq)
 
 
 def _check_channels(chs: Sequence[int]) -> None:

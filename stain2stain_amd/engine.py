@@ -58,6 +58,23 @@ class SyncBNExchange:
 
 
 sync_bn: Optional[SyncBNExchange] = None      # set for the duration of a training step (sync_batchnorm below)
+_module_exchanges: Dict[int, SyncBNExchange] = {}
+
+
+def _module_exchange(bn: torch.nn.Module) -> Optional[SyncBNExchange]:
+    """A BatchNorm container that has been converted by ``torch.nn.SyncBatchNorm.convert_sync_batchnorm`` (Lightning's
+    ``sync_batchnorm: True``, configs/trainer/ddp.yaml:9) synchronises over its own process group, as the torch module
+    would: in training, when torch.distributed is up and the group has more than one rank (S2S_FORCE_DDP=1: any)."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not (dist.is_available() and dist.is_initialized()):
+        return None
+    pg = bn.process_group
+    import os
+    if dist.get_world_size(pg) < 2 and os.environ.get("S2S_FORCE_DDP") != "1":
+        return None
+    key = id(pg) if pg is not None else 0
+    if key not in _module_exchanges:
+        _module_exchanges[key] = SyncBNExchange(pg)
+    return _module_exchanges[key]
 
 
 @contextlib.contextmanager
@@ -81,13 +98,22 @@ mutation_epoch = [0]     # see ConvBN.eval_affine
 class ConvBN:
     """One Conv3x3 + BatchNorm2d pair of a DoubleConv, with its packed MFMA weight cache."""
 
-    def __init__(self, prefix: str, i_conv: str, i_bn: str, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d):
+    def __init__(self, prefix: str, i_conv: str, i_bn: str, seq: torch.nn.Sequential):
         self.prefix = prefix            # e.g. "inc.double_conv"; parameter names are f"{prefix}.{i_conv}.weight" ...
         self.idx = (i_conv, i_bn)       # ("0", "1") or ("3", "4"): positions inside the reference's nn.Sequential
-        self.conv, self.bn = conv, bn
+        self._seq = seq                 # looked up on every use: torch.nn.SyncBatchNorm.convert_sync_batchnorm (what
+                                        # Lightning's sync_batchnorm: True calls) REPLACES the BatchNorm2d in the container
         self._pack: Dict[torch.dtype, Tuple] = {}
         self._pack_key: Dict[torch.dtype, Tuple] = {}
         self._eval_key, self._eval_ss = None, None
+
+    @property
+    def conv(self) -> torch.nn.Conv2d:
+        return self._seq._modules[self.idx[0]]
+
+    @property
+    def bn(self) -> torch.nn.BatchNorm2d:
+        return self._seq._modules[self.idx[1]]
 
     @property
     def cout(self) -> int:
@@ -186,7 +212,7 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         else:
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
         count = raw.shape[0] * raw.shape[1] * raw.shape[2]
-        sx = sync_bn
+        sx = sync_bn if sync_bn is not None else _module_exchange(bn)
         if sx is not None:      # statistics over the global batch: all-reduce the per-channel sums, finalize on those
             sums = ops.bn_partial_sums(stat)
             sx(sums)

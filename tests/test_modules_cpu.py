@@ -144,3 +144,19 @@ def test_generate_follows_the_reference_mode_and_solver_rules(monkeypatch):
     mt.train()
     img, pm = mt.generate(x, num_steps=4)
     assert not mt.training and img.shape == x.shape and pm.shape == (2, 1, 4, 4)
+
+
+def test_converted_syncbatchnorm_containers_are_seen_by_the_engine():
+    """Lightning's `sync_batchnorm: True` (configs/trainer/ddp.yaml:9) calls torch.nn.SyncBatchNorm.convert_sync_batchnorm,
+    which REPLACES the BatchNorm2d modules inside the DoubleConv containers: the engine's layer bundles look their modules
+    up on every use (same Parameter objects, same state_dict keys), and without a process group nothing synchronises."""
+    import torch
+    from stain2stain_amd import FlowUNet, engine
+    net = FlowUNet(3, [16, 32], 3, 32)
+    keys = list(net.state_dict().keys())
+    w = net.encoder._blocks[0][0].bn.weight
+    net2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    cb = net2.encoder._blocks[0][0]
+    assert isinstance(cb.bn, torch.nn.SyncBatchNorm) and cb.bn.weight is w and list(net2.state_dict().keys()) == keys
+    assert engine._module_exchange(cb.bn) is None            # torch.distributed not initialised: local statistics
+    assert engine._module_exchange(torch.nn.BatchNorm2d(8)) is None

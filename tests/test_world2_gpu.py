@@ -9,6 +9,7 @@ What this pins, that the CPU gloo tests of the host logic (tests/test_ddp_cpu.py
     stain experiments' setting: configs/experiment/gray_matter/simple_flow_matching.yaml:18-23),
   * reduce-scatter + sharded Adam + parameter all-gather gives bit-identical parameters,
   * SyncBatchNorm (configs/trainer/ddp.yaml:9): two ranks x 4 tiles == one process x 8 tiles (full-batch statistics),
+    by the trainer's flag and by torch.nn.SyncBatchNorm.convert_sync_batchnorm on the module (Lightning's route),
   * the pix2pix G + D step (InstanceNorm: per sample): two ranks x 2 tiles == one process x 4 tiles.
 Reference behaviour: DDP mean of gradients (configs/trainer/ddp.yaml:4), rank r takes ``batch_size // world_size`` tiles
 (src/data/paired_data_module.py:273-278)."""
@@ -77,8 +78,11 @@ def _rank_main(rank, world, port, out_dir):
     res = {}
     x0, x1, t = _data(world * PER_RANK)
     lo, hi = rank * PER_RANK, (rank + 1) * PER_RANK
-    for name, kw in (("ddp", {}), ("sharded", {"sharded_optimizer": True}), ("syncbn", {"sync_batchnorm": True})):
+    for name, kw in (("ddp", {}), ("sharded", {"sharded_optimizer": True}), ("syncbn", {"sync_batchnorm": True}),
+                     ("converted", {})):
         net = _unet(100 + rank)                    # replicas start DIFFERENT: the constructor broadcasts rank 0's
+        if name == "converted":                    # what Lightning does for `sync_batchnorm: True`
+            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         tr = CFMTrainer(net, lr=LR, weight_decay=1e-5, **kw)
         assert tr.bucketer.enabled and tr.bucketer.world == world
         res[name] = _cfm_steps(tr, net, x0[lo:hi], x1[lo:hi], t[:, lo:hi])
@@ -165,6 +169,10 @@ def test_syncbatchnorm_two_ranks_equal_one_process_on_the_global_batch(ranks):
     for r in (0, 1):                      # running statistics of the GLOBAL batch on every rank
         for k, v in ref["buffers"].items():
             _close(ranks[r]["syncbn"]["buffers"][k].float(), v.float(), 1e-5, k)
+    # Lightning's route -- torch.nn.SyncBatchNorm.convert_sync_batchnorm on the module, no trainer flag -- is the same step
+    for r in (0, 1):
+        assert torch.equal(ranks[r]["converted"]["param"], ranks[r]["syncbn"]["param"])
+        assert ranks[r]["converted"]["loss"] == ranks[r]["syncbn"]["loss"]
     # and it is not what per-replica statistics give
     assert float((ranks[0]["syncbn"]["grad"] - ranks[0]["ddp"]["grad"]).abs().max()) > 1e-3 * float(ref["grad"].abs().max())
 
