@@ -2,7 +2,8 @@
 the convolution parity tests in child processes, so that a non-default path cannot rot unnoticed:
   S2S_WGRAD_KH=1 / 2      kernel rows of the weight gradient over three workgroups / over the teams of a 12-wave workgroup
   S2S_CONV_XCD=0, S2S_WGRAD_XCD=0   plain (not XCD-aware) workgroup order
-  S2S_WGRAD_DMA=0         register-staged weight gradient"""
+  S2S_WGRAD_DMA=0         register-staged weight gradient
+  S2S_WGRAD_MFMA=16       weight gradient on 16x16x32 MFMAs (half-swapped LDS rows)"""
 import os
 import subprocess
 import sys
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = [{"S2S_WGRAD_KH": "1"}, {"S2S_WGRAD_KH": "2"}, {"S2S_CONV_XCD": "0", "S2S_WGRAD_XCD": "0"},
-            {"S2S_WGRAD_DMA": "0"}]
+            {"S2S_WGRAD_DMA": "0"}, {"S2S_WGRAD_MFMA": "16"}]
 # (S2S_CONV_DMA=1/3/0, the earlier forms of the forward loop kept for ablations, take BatchNorm's partial sums from the
 #  fp32 accumulators rather than from the stored bf16 values and have no split-K form: not held to these tests.)
 
