@@ -158,6 +158,62 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
   }
 }
 
+// The same gather with a FIXED 5 x 5 window of unconditional loads (maps wider than 3 source pixels per axis).  The
+// rows that read source row iy are those whose i0 is iy - 1 or iy: consecutive, and at most five of them when
+// 2 (2 Hin - 1) / (Hin - 1) < 5, i.e. Hin > 3.  The first one is found by walking the forward's own index arithmetic up
+// from a conservative estimate (no loads), the five weights follow from it (zero where a row does not contribute or
+// falls outside), and the 25 loads of a thread are independent of any weight test, so they are all in flight at once;
+// the loop above issues each load behind a data-dependent branch and is latency-bound (2.3 TB/s).
+__device__ __forceinline__ float ac_weight_of(int dst, int n_in, float scale, int src_index) {
+  const Axis a = ac_axis(dst, n_in, scale);
+  return (a.i0 == src_index ? a.w0 : 0.f) + (a.i1 == src_index ? a.w1 : 0.f);
+}
+
+template <typename T>
+__global__ void upsample2x_bwd_win_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int B,
+                                          int Hin, int Win, int Hout, int Wout, int padT, int padL, int C) {
+  const int cp = C >> 3;
+  const int Hu = 2 * Hin, Wu = 2 * Win;
+  const float sh = (float)(Hin - 1) / (float)(Hu - 1), sw = (float)(Win - 1) / (float)(Wu - 1);
+  const int total = B * Hin * Win * cp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int t0 = i / cp, c8 = (i - t0 * cp) * 8;
+    const int t1 = t0 / Win, ix = t0 - t1 * Win;
+    const int n = t1 / Hin, iy = t1 - n * Hin;
+    int uy0 = (int)floorf((float)(iy - 1) / sh) - 1, ux0 = (int)floorf((float)(ix - 1) / sw) - 1;
+    if (uy0 < 0) uy0 = 0;
+    if (ux0 < 0) ux0 = 0;
+    for (int t = 0; t < 8 && uy0 < Hu - 1 && ac_weight_of(uy0, Hin, sh, iy) == 0.f; ++t) ++uy0;
+    for (int t = 0; t < 8 && ux0 < Wu - 1 && ac_weight_of(ux0, Win, sw, ix) == 0.f; ++t) ++ux0;
+    float wy[5], wx[5];
+    int oyc[5], oxc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int uy = uy0 + j, ux = ux0 + j;
+      const int oy = uy + padT, ox = ux + padL;
+      wy[j] = (uy <= Hu - 1 && oy >= 0 && oy < Hout) ? ac_weight_of(uy, Hin, sh, iy) : 0.f;
+      wx[j] = (ux <= Wu - 1 && ox >= 0 && ox < Wout) ? ac_weight_of(ux, Win, sw, ix) : 0.f;
+      oyc[j] = oy < 0 ? 0 : (oy > Hout - 1 ? Hout - 1 : oy);
+      oxc[j] = ox < 0 ? 0 : (ox > Wout - 1 ? Wout - 1 : ox);
+    }
+    f32x8 acc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const T* const rowp = dy + ((long)n * Hout + oyc[j]) * Wout * lddy + c8;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const f32x8 g = load8(rowp + (long)oxc[m] * lddy);
+        const float w = wy[j] * wx[m];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.v[k] = fmaf(w, g.v[k], acc.v[k]);
+      }
+    }
+    store8(dx + (((long)n * Hin + iy) * Win + ix) * lddx + c8, acc);
+  }
+}
+
 // out[n][c] (+)= sum over the H*W pixels of x[n][.][.][c]   (gradient of the broadcast time bias)
 template <typename T>
 __global__ void pixel_sum_kernel(const T* __restrict__ x, int ldx, float* __restrict__ out, int HW, int C,
@@ -219,13 +275,15 @@ extern "C" int s2s_upsample2x_bilinear_ac_bwd(int dtype, const void* dy, int ldd
   if (total >= (1L << 31) - (1L << 22)) return S2S_ERR_SHAPE;   // 32-bit element index in the kernel
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ew_grid(total));
-  if (dtype == S2S_BF16)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy,
-                       (bf16_t*)dx, lddx, B, Hin, Win, Hout, Wout, padT, padL, C);
-  else if (dtype == S2S_F32)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy,
-                       (float*)dx, lddx, B, Hin, Win, Hout, Wout, padT, padL, C);
-  else return S2S_ERR_DTYPE;
+  static const int windowed = [] { const char* e = getenv("S2S_UP_BWD_WIN"); return e ? atoi(e) : 1; }();
+  const bool win = windowed && Hin > 3 && Win > 3;       // at most five contributing rows / columns per source pixel
+  if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
+#define S2S_UPB(KERN, TT)                                                                                            \
+  hipLaunchKernelGGL(KERN<TT>, grid, dim3(256), 0, s, (const TT*)dy, lddy, (TT*)dx, lddx, B, Hin, Win, Hout, Wout,   \
+                     padT, padL, C)
+  if (dtype == S2S_BF16) { if (win) S2S_UPB(upsample2x_bwd_win_kernel, bf16_t); else S2S_UPB(upsample2x_bwd_kernel, bf16_t); }
+  else { if (win) S2S_UPB(upsample2x_bwd_win_kernel, float); else S2S_UPB(upsample2x_bwd_kernel, float); }
+#undef S2S_UPB
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
