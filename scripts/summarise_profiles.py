@@ -31,7 +31,7 @@ groups = {"conv3x3_mfma (fwd+dgrad, conv3x3_dma16_kernel)": "conv3x3_dma16_kerne
           "conv3x3_wgrad (conv3x3_wgrad_dma_kernel)": "conv3x3_wgrad_dma_kernel",
           "bn_relu_apply": "bn_relu_apply_kernel", "bn_relu_bwd_reduce_flat": "bn_relu_bwd_reduce_flat_kernel",
           "bn_relu_bwd_apply_flat": "bn_relu_bwd_apply_flat_kernel", "upsample2x_fwd": "upsample2x_fwd_kernel",
-          "upsample2x_bwd": "upsample2x_bwd_kernel", "adam": "adam_kernel", "head_loss": "head_loss_lanes_kernel"}
+          "upsample2x_bwd": "upsample2x_bwd_", "adam": "adam_kernel", "head_loss": "head_loss_lanes_kernel"}
 out = {}
 for label, needle in groups.items():
     f = [v for k, vs in fetch.items() if needle in k for v in vs]

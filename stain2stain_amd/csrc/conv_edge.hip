@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void head_loss_lanes_kernel(const T* __restric
                                                               T* __restrict__ dx, int lddx, float coef,
                                                               float* __restrict__ part, double* __restrict__ lpart,
                                                               long npix, int HW, int Cout) {
-  constexpr int C = PCB * 8, PPB = 256 / PCB, MO = HEAD_MAX_COUT;
+  constexpr int C = PCB * 8, PPB = 256 / PCB, MO = HEAD_MAX_COUT;      // (loops over 3 instead of 4 outputs: no faster)
   __shared__ float fold[256][MO * 8 + 1];
   __shared__ float dbf[PPB][MO];
   __shared__ double lred[256];
@@ -463,14 +463,25 @@ __global__ __launch_bounds__(256) void head_loss_lanes_kernel(const T* __restric
     for (int k = 0; k < 8; ++k) dwacc[o][k] = 0.f;
   }
   double lsum = 0.0;
-  for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
-    const long p = p0 + slot;
-    const bool ok = p < npix;
-    f32x8 a;
-    if (ok) a = load8(x + p * ldx + pc * 8);
-    else {
+  // the next pixel's piece is fetched before this one is processed (one load in flight per thread left the loop
+  // latency-bound: 2.4 TB/s); pixel indices fit 32 bits (checked on the host), so n = p / HW is a 32-bit division
+  const int np = (int)npix, stride = (int)gridDim.x * PPB;
+  f32x8 a_next;
+  {
+    const int pf = (int)blockIdx.x * PPB + slot;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
+    for (int k = 0; k < 8; ++k) a_next.v[k] = 0.f;
+    if (pf < np) a_next = load8(x + (long)pf * ldx + pc * 8);
+  }
+  for (int p0 = (int)blockIdx.x * PPB; p0 < np; p0 += stride) {
+    const int p = p0 + slot;
+    const bool ok = p < np;
+    const f32x8 a = a_next;
+    {
+      const int pn = p + stride;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a_next.v[k] = 0.f;
+      if (p0 + stride < np && pn < np) a_next = load8(x + (long)pn * ldx + pc * 8);
     }
     float vv[MO];
 #pragma unroll
@@ -482,13 +493,13 @@ __global__ __launch_bounds__(256) void head_loss_lanes_kernel(const T* __restric
       for (int m = 1; m < PCB; m <<= 1) t += __shfl_xor(t, m, 64);
       vv[o] = t + bo[o];
     }
-    const long n = p / HW, q = p - n * HW;
+    const int n = p / HW, q = p - n * HW;
     float gm[MO];
 #pragma unroll
     for (int o = 0; o < MO; ++o) {
       gm[o] = 0.f;
       if (ok && o < Cout && (o & (PCB - 1)) == pc) {        // this lane owns output channel o of the pixel
-        const long idx = (n * Cout + o) * HW + q;
+        const long idx = ((long)n * Cout + o) * HW + q;
         if (v_out) v_out[idx] = vv[o];
         const float d = vv[o] - u[idx];
         lsum += (double)(d * d);
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) void head_loss_lanes_kernel(const T* __restric
         for (int o = 0; o < MO; ++o) t = fmaf(g[o], wr[o][k], t);
         da.v[k] = t;
       }
-      store8(dx + p * lddx + pc * 8, da);
+      store8(dx + (long)p * lddx + pc * 8, da);
     }
 #pragma unroll
     for (int o = 0; o < MO; ++o) {
@@ -682,6 +693,7 @@ extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const floa
     return S2S_ERR_SHAPE;
   if (Cout * (C + 1) > 1024) return S2S_ERR_SHAPE;
   const long npix = (long)B * H * W;
+  if (npix >= (1L << 31) - (1L << 20)) return S2S_ERR_SHAPE;       // 32-bit pixel index (+ one grid stride) in the kernel
   const double count = (double)npix * Cout;
   const int nb = s2s_head_loss_blocks(B, H, W);
   const int lds = (HEAD_MAX_COUT * C + 256 * HEAD_MAX_COUT) * 4 + 256 * (C + 8) * 2;
