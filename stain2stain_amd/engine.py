@@ -72,9 +72,10 @@ def _module_exchange(bn: torch.nn.Module) -> Optional[SyncBNExchange]:
     if dist.get_world_size(pg) < 2 and os.environ.get("S2S_FORCE_DDP") != "1":
         return None
     key = id(pg) if pg is not None else 0
-    if key not in _module_exchanges:
-        _module_exchanges[key] = SyncBNExchange(pg)
-    return _module_exchanges[key]
+    ex = _module_exchanges.get(key)
+    if ex is None or ex.pg is not pg:          # (an id can be re-used by a later group: the entry holds its own group)
+        ex = _module_exchanges[key] = SyncBNExchange(pg)
+    return ex
 
 
 @contextlib.contextmanager
