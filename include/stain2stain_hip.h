@@ -371,6 +371,13 @@ int s2s_p2p_act_bwd(int dtype, const void* g, int ldg, const void* g2, int ldg2,
  * stream of the fused trainers; any hipStream_t may be passed as `stream` to every entry point above. */
 int s2s_stream_create_cu_mask(const unsigned* mask_words, int n_words, long* out_stream);
 int s2s_stream_destroy(void* stream);
+/* Events for timing brackets: timing_only != 0 creates the event with hipEventDisableSystemFence (a timestamp marker
+ * without the system-scope fence of a default event); elapsed_ms wants both events complete. */
+int s2s_event_create(int timing_only, long* out_event);
+int s2s_event_record(void* event, void* stream);
+int s2s_event_elapsed_ms(void* start, void* stop, float* out_ms);
+int s2s_event_synchronize(void* event);
+int s2s_event_destroy(void* event);
 
 #ifdef __cplusplus
 }

@@ -28,3 +28,36 @@ extern "C" int s2s_stream_destroy(void* stream) {
   if (!stream) return S2S_ERR_NULL;
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? S2S_OK : S2S_ERR_LAUNCH;
 }
+
+// Timing-only events for the per-kernel brackets of bench.py (ops._timed).  A default HIP event performs a system-scope
+// release fence when it completes (so that the host may read what the stream wrote); hipEventDisableSystemFence drops
+// it for events that only carry a timestamp, which takes most of the marker's cost off the bracketed kernel.
+extern "C" int s2s_event_create(int timing_only, long* out_event) {
+  if (!out_event) return S2S_ERR_NULL;
+  hipEvent_t e = nullptr;
+  const unsigned flags = timing_only ? hipEventDisableSystemFence : hipEventDefault;
+  if (hipEventCreateWithFlags(&e, flags) != hipSuccess) { (void)hipGetLastError(); return S2S_ERR_LAUNCH; }
+  *out_event = (long)(uintptr_t)e;
+  return S2S_OK;
+}
+
+extern "C" int s2s_event_record(void* event, void* stream) {
+  if (!event) return S2S_ERR_NULL;
+  return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? S2S_OK : S2S_ERR_LAUNCH;
+}
+
+// milliseconds between two recorded events (both complete: synchronise the stream or the later event first)
+extern "C" int s2s_event_elapsed_ms(void* start, void* stop, float* out_ms) {
+  if (!start || !stop || !out_ms) return S2S_ERR_NULL;
+  return hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? S2S_OK : S2S_ERR_LAUNCH;
+}
+
+extern "C" int s2s_event_synchronize(void* event) {
+  if (!event) return S2S_ERR_NULL;
+  return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? S2S_OK : S2S_ERR_LAUNCH;
+}
+
+extern "C" int s2s_event_destroy(void* event) {
+  if (!event) return S2S_ERR_NULL;
+  return hipEventDestroy((hipEvent_t)event) == hipSuccess ? S2S_OK : S2S_ERR_LAUNCH;
+}

@@ -8,6 +8,9 @@ RuntimeError (the reference's only error convention is Python exceptions, src/ut
 """
 from __future__ import annotations
 
+import ctypes
+import os
+import sys
 from typing import Optional, Tuple
 
 import torch
@@ -135,6 +138,38 @@ def side_stream_for(device) -> Optional[torch.cuda.Stream]:
     return torch.cuda.Stream(device=device)
 
 
+class TimingEvent:
+    """A HIP event that only carries a timestamp (``s2s_event_create(timing_only=1)``: no system-scope fence when it
+    completes), with the two methods of ``torch.cuda.Event`` the brackets use.  S2S_TIMING_EVENTS=0: torch's events."""
+
+    def __init__(self):
+        out = ctypes.c_long(0)
+        _native.check(_L().s2s_event_create(1, ctypes.addressof(out)), "event_create")
+        self._e = out.value
+
+    def record(self) -> None:
+        _native.check(_L().s2s_event_record(self._e, _stream()), "event_record")
+
+    def elapsed_time(self, end: "TimingEvent") -> float:
+        ms = ctypes.c_float(0.0)
+        _native.check(_L().s2s_event_synchronize(end._e), "event_synchronize")
+        _native.check(_L().s2s_event_elapsed_ms(self._e, end._e, ctypes.addressof(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._e and not sys.is_finalizing():
+                _L().s2s_event_destroy(self._e)
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _timing_event():
+    if os.environ.get("S2S_TIMING_EVENTS", "1") == "0":
+        return torch.cuda.Event(enable_timing=True)
+    return TimingEvent()
+
+
 def profile_stop() -> list:
     """[(op name, algorithmic work, start event, end event)] recorded since profile_start()."""
     global _PROFILE
@@ -147,8 +182,8 @@ def _timed(name: str, work_fn=None):
         def wrapped(*args, **kwargs):
             if _PROFILE is None or (_PROFILE_ONLY is not None and name not in _PROFILE_ONLY):
                 return fn(*args, **kwargs)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+            e0 = _timing_event()
+            e1 = _timing_event()
             e0.record()
             out = fn(*args, **kwargs)
             e1.record()
@@ -232,8 +267,8 @@ def conv3x3_wgrad(dy: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor]
         # event-bracketed: the split MFMA kernel and the fold of its slabs as two launches, each timed on its own
         # (rocprofv3 lists them as two kernels; the product path below issues them from one call)
         for name, phase, work in (("conv3x3_wgrad_mfma", 1, _wgrad_flops(dy, x0, x1, grad_oihw)), ("wgrad_fold", 2, 0.0)):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+            e0 = _timing_event()
+            e1 = _timing_event()
             e0.record()
             rc = _L().s2s_conv3x3_wgrad_phase(dt, pdy, lddy, cout, p0, ld0, c0, p1, ld1, c1, _f32(part), _f32(grad_oihw),
                                               int(accumulate), B, H, W, phase, _stream())

@@ -345,6 +345,26 @@ def test_head_loss_fused_matches_separate_ops(dtype, C):
     assert relerr(db.cpu(), b.grad) < 1e-4
 
 
+def test_timing_only_events_bracket_a_kernel():
+    """s2s_event_*: the timestamp-only events of bench.py's per-kernel brackets (no system-scope fence) measure the same
+    stream interval as torch's events around the same launches, to well within a launch time."""
+    from stain2stain_amd import ops
+    x = torch.zeros(1 << 24, device="cuda")
+    y = torch.ones(1 << 24, device="cuda")
+    for _ in range(3):
+        ops.axpy_(x, y, 1.0)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = ops.TimingEvent(), ops.TimingEvent()
+    t0.record(); e0.record()
+    for _ in range(20):
+        ops.axpy_(x, y, 1.0)
+    e1.record(); t1.record()
+    torch.cuda.synchronize()
+    ms, ms_torch = e0.elapsed_time(e1), t0.elapsed_time(t1)
+    assert 0.0 < ms <= ms_torch * 1.05 + 0.02 and ms > 0.5 * ms_torch, (ms, ms_torch)
+    assert float(x[0]) == 23.0
+
+
 def test_cu_masked_stream_runs_kernels():
     """s2s_stream_create_cu_mask: a stream confined to three quarters of the CUs runs a conv launch to the same bits as
     the default stream (engine.run_on_side's stream when S2S_WGRAD_CUS is set); bad specs are refused.  In a child
