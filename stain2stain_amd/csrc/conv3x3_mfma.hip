@@ -826,6 +826,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   const int c_lo = (int)(((long)blockIdx.z * a.nchunk) / gridDim.z), c_hi = (int)(((long)(blockIdx.z + 1) * a.nchunk) / gridDim.z);
 
   const int drow = lane >> 2, dslot = lane & 3;
+  // 16-byte slot of a halo pixel's 64-byte row: piece ^ key(halo column).  The three taps of a kernel row read the
+  // fragments at columns c, c + 1, c + 2, and a ds_read_b128 lane group mixes rows {0-3, 12-15} of one piece with rows
+  // {4-11} of the next: the key 2 * ((column >> 2) & 1) keeps the sixteen slots of every such group distinct for all
+  // three shifts (exhaustive check over shifts, row blocks and lane groups); the earlier (-(column >> 2)) & 3 was only
+  // conflict-free unshifted, and SQ_LDS_BANK_CONFLICT showed 29 % of this kernel's LDS cycles as conflicts
+  // (profiles/r02_f_sq_counters.json; S2S_CONV_DBG=128 selects the old key).
+  const bool old_key = (a.dbg & 128) != 0;
+  auto akey = [&](int col) { return old_key ? ((-(col >> 2)) & 3) : (((col >> 2) & 1) << 1); };
   int apix[HG], apc[HG];
 #pragma unroll
   for (int j = 0; j < HG; ++j) {
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     const int gy = y0 - 1 + hy, gx = x0p - 1 + hx;
     apix[j] = (row < ROWS && hx < TW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                   ? (img * a.H + gy) * a.W + gx : -1;
-    apc[j] = (dslot ^ ((-(hx >> 2)) & 3)) * 8;
+    apc[j] = (dslot ^ akey(hx)) * 8;
   }
   const char* wptr[BG];
   int wstep[BG];
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int px = rb * 16 + cl + kw;
-      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ ((-(px >> 2)) & 3)) << 4);
+      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ akey(px)) << 4);
     }
   const int nrow = wn * WTN + cl;
   const int bofs = nrow * 64 + ((kp ^ ((-(nrow >> 2)) & 3)) << 4);   // + ni*16*64 (same swizzle phase)
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
     const bool inside = row < ROWS && hx < TW + KS - 1 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
     if (MODE == 1) apix[j] = inside ? ((gy << 16) | gx) : -1;        // cell coordinates; the pixel depends on the chunk
     else apix[j] = inside ? (img * Hi + gy) * Wi + gx : -1;
-    apc[j] = (dslot ^ ((-(hx >> 2)) & 3)) * 8;
+    apc[j] = (dslot ^ (((hx >> 2) & 1) << 1)) * 8;      // slot key of the halo column: see conv3x3_dma16_kernel
   }
   const char* wptr[BG];
   int wstep[BG];
@@ -1111,7 +1119,7 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
 #pragma unroll
     for (int kw = 0; kw < KS; ++kw) {
       const int px = rb * 16 + cl + kw;
-      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ ((-(px >> 2)) & 3)) << 4);
+      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ (((px >> 2) & 1) << 1)) << 4);
     }
   const int nrow = wn * WTN + cl;
   const int bofs = nrow * 64 + ((kp ^ ((-(nrow >> 2)) & 3)) << 4);
