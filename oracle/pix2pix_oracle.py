@@ -80,21 +80,26 @@ class OracleGenerator(torch.nn.Module):
 
 
 class OracleDiscriminator(torch.nn.Module):
-    def __init__(self, in_channels=6, ndf=64):
+    """Same architecture and parameter names as stain2stain_amd.pix2pix.PatchGANDiscriminator (``n_layers = 3``: the
+    70x70 PatchGAN c1 ... c5), on nn.Conv2d + F.instance_norm in fp32."""
+
+    def __init__(self, in_channels=6, ndf=64, n_layers=3):
         super().__init__()
         nn = torch.nn
+        self.n_layers = n_layers
         self.c1 = nn.Conv2d(8, ndf, 4, 2, 1)
-        self.c2 = nn.Conv2d(ndf, 2 * ndf, 4, 2, 1)
-        self.c3 = nn.Conv2d(2 * ndf, 4 * ndf, 4, 2, 1)
-        self.c4 = nn.Conv2d(4 * ndf, 8 * ndf, 4, 1, 1)
-        self.c5 = nn.Conv2d(8 * ndf, 8, 4, 1, 1)
+        cin = ndf
+        for n in range(1, n_layers + 1):
+            cout = ndf * min(2 ** n, 8)
+            setattr(self, f"c{n + 1}", nn.Conv2d(cin, cout, 4, 1 if n == n_layers else 2, 1))
+            cin = cout
+        setattr(self, f"c{n_layers + 2}", nn.Conv2d(cin, 8, 4, 1, 1))
 
     def forward(self, a, b):
         F = torch.nn.functional
         x = torch.cat([a, b], 1)
         x = F.pad(x, (0, 0, 0, 0, 0, 8 - x.shape[1]))
         h = F.leaky_relu(self.c1(x), 0.2)
-        h = F.leaky_relu(F.instance_norm(self.c2(h)), 0.2)
-        h = F.leaky_relu(F.instance_norm(self.c3(h)), 0.2)
-        h = F.leaky_relu(F.instance_norm(self.c4(h)), 0.2)
-        return self.c5(h)[:, :1]
+        for k in range(2, self.n_layers + 2):
+            h = F.leaky_relu(F.instance_norm(getattr(self, f"c{k}")(h)), 0.2)
+        return getattr(self, f"c{self.n_layers + 2}")(h)[:, :1]

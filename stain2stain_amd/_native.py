@@ -14,6 +14,8 @@ from typing import Dict, List, Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libstain2stain_hip.so")
+# scripts/ only: the same sources with -DS2S_ABLATE (superseded forward loops, result-changing timing ablations)
+ABLATE_LIB_PATH = os.path.join(HERE, "libstain2stain_hip_ablate.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "stain2stain_hip.h")
 SOURCES = ["conv3x3_mfma.hip", "conv3x3_wgrad_mfma.hip", "conv_edge.hip", "norm_act.hip", "resample.hip",
            "flow.hip", "optim.hip", "input_pipeline.hip", "seg_loss.hip", "loss_variants.hip", "instnorm.hip", "pix2pix.hip",
@@ -40,13 +42,19 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, jobs: int = 4) -> str:
-    """Compile every HIP source for gfx950 and link the shared library in-tree."""
+def build(force: bool = False, verbose: bool = False, jobs: int = 4, ablate: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library in-tree.  ``ablate``: the -DS2S_ABLATE variant
+    (libstain2stain_hip_ablate.so, for scripts/ -- set S2S_LIB=ablate before importing the package to load it)."""
+    if ablate:
+        return _build_to(ABLATE_LIB_PATH, os.path.join(HERE, "build_ablate"), ["-DS2S_ABLATE"], True, verbose, jobs)
     if not force and not needs_build():
         return LIB_PATH
-    objdir = os.path.join(HERE, "build")
+    return _build_to(LIB_PATH, os.path.join(HERE, "build"), [], force, verbose, jobs)
+
+
+def _build_to(lib_path: str, objdir: str, extra: List[str], force: bool, verbose: bool, jobs: int) -> str:
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", *extra]
     procs = []
     objs = []
     for src in SOURCES:
@@ -63,13 +71,13 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 4) -> str:
         if len(procs) >= jobs:
             _drain(procs)
     _drain(procs)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     if verbose:
         print(" ".join(cmd))
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if out.returncode != 0:
         raise RuntimeError("link failed:\n" + out.stdout.decode())
-    return LIB_PATH
+    return lib_path
 
 
 def _drain(procs: List) -> None:
@@ -111,7 +119,11 @@ def lib() -> ctypes.CDLL:
     """Load (never build implicitly on a GPU box unless the .so is missing) and return the library."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if os.environ.get("S2S_LIB") == "ablate":          # scripts/ only (timing ablations; results may be wrong)
+            if not os.path.exists(ABLATE_LIB_PATH):
+                build(ablate=True)
+            _lib = ctypes.CDLL(ABLATE_LIB_PATH)
+        elif not os.path.exists(LIB_PATH):
             import fcntl                   # one rank of a multi-process launch builds, the others wait for it
             with open(os.path.join(HERE, ".build.lock"), "w") as lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
@@ -120,10 +132,11 @@ def lib() -> ctypes.CDLL:
                         build()
                 finally:
                     fcntl.flock(lock, fcntl.LOCK_UN)
-        try:
-            _lib = ctypes.CDLL(LIB_PATH)
-        except OSError as e:  # loud failure: there is no CPU / eager path behind these ops
-            raise RuntimeError(f"stain2stain_amd: cannot load {LIB_PATH}: {e}") from e
+        if _lib is None:
+            try:
+                _lib = ctypes.CDLL(LIB_PATH)
+            except OSError as e:  # loud failure: there is no CPU / eager path behind these ops
+                raise RuntimeError(f"stain2stain_amd: cannot load {LIB_PATH}: {e}") from e
         for name, (restype, argtypes) in declared_prototypes().items():
             fn = getattr(_lib, name)
             fn.restype = restype

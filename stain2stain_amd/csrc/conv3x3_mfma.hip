@@ -32,6 +32,17 @@
 #include <type_traits>
 #include <utility>
 
+// Timing ablations that change results (skip a DMA, the MFMAs, the stores ...) and the superseded forward loops are
+// compiled only with -DS2S_ABLATE (stain2stain_amd/_native.py build(ablate=True) -> libstain2stain_hip_ablate.so, used by
+// scripts/ alone); the product library cannot be switched into them by an environment variable.
+#ifdef S2S_ABLATE
+#define S2S_ABL(cond) (cond)
+#define S2S_DBG_MASK (~0)
+#else
+#define S2S_ABL(cond) false
+#define S2S_DBG_MASK (64 | 128)
+#endif
+
 struct Conv3x3Args {
   const void* x0;
   const void* x1;
@@ -65,7 +76,8 @@ struct Conv3x3Args {
   // every XCD has its own L2, so the grid is cut into xsp x xsn = 8 blocks (pixel-tile ranges x output-channel-tile
   // ranges), one per XCD, walked output-channel tile fastest; xsp = 0 = the plain order.
   int xsp, xsn;
-  int dbg;   // timing experiments only (S2S_CONV_DBG): bit0 = no weight DMA in the loop, bit1 = no MFMA, bit2 = no halo DMA
+  int dbg;   // S2S_CONV_DBG: 64 = clock probe, 128 = old LDS slot key; -DS2S_ABLATE builds only: bit0 = no weight DMA in the
+             // 32x32x16 loop, bit1 = no MFMA, bit2 = no halo DMA, 8 = no global stores, 16 = no epilogue
 };
 
 namespace {
@@ -463,6 +475,7 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef S2S_ABLATE   // the 32x32x16 form of the LDS-DMA loop: ablation builds only (scripts/), never in the product library
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
   using T = bf16_t;
@@ -631,6 +644,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(Conv3x3Args a) {
   conv_epilogue<T, TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES>(a, acc, smem, img, y0, x0p, n0);
 }
 
+#endif  // S2S_ABLATE
+
 // =========================================================================================================
 // bf16 main loop v3: the LDS-DMA loop above on v_mfma_f32_16x16x32_bf16.  One MFMA covers the whole 32-channel
 // chunk of a tap (K = 32), a lane's A/B fragment is one 16-B piece (row = lane & 15, piece = lane >> 4), and the
@@ -732,7 +747,7 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
       if (full || (gy < a.H && gx < a.W && n < a.Cout)) {
         const bf16x8 val = *reinterpret_cast<const bf16x8*>(otile + ml * RS + c * 16);
         const long opix = ((long)img * om.OH + gy * om.os + om.oy) * om.OW + gx * om.os + om.ox;
-        if (!(a.dbg & 8)) *reinterpret_cast<bf16x8*>(yout + opix * a.ldy + n) = val;
+        if (!S2S_ABL(a.dbg & 8)) *reinterpret_cast<bf16x8*>(yout + opix * a.ldy + n) = val;
         if (a.y2) {
           bf16x8 r8;
 #pragma unroll
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_s_barrier();
     });
   }
-  if (a.dbg & 16) return;
+  if (S2S_ABL(a.dbg & 16)) return;
   if (a.kpart) {
     float* const kpz = a.kpart + (long)blockIdx.z * ((long)a.B * a.H * a.W) * a.Cout;
 #pragma unroll
@@ -1454,6 +1469,7 @@ __global__ __launch_bounds__(256) void convk_splitk_reduce_kernel(Conv3x3Args a,
   }
 }
 
+#ifdef S2S_ABLATE
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 int launch_dma(Conv3x3Args& a, hipStream_t s) {
   constexpr int ROWS = (TH + 2) * (TW + 4);
@@ -1475,6 +1491,8 @@ int launch_dma(Conv3x3Args& a, hipStream_t s) {
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
+
+#endif  // S2S_ABLATE
 
 template <typename T, int TH, int TW, int BN, int WM, int WN, int KS = 3, int PAD = 1>
 int launch_cfg(Conv3x3Args& a, hipStream_t s) {
@@ -1672,22 +1690,11 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
     if (id == 1) return launch_cfg<float, 8, 16, 64, 2, 2>(a, s);
     return launch_cfg<float, 4, 32, 64, 2, 2>(a, s);
   }
-  // 16 = LDS-DMA loop on v_mfma_f32_16x16x32_bf16 (default), 1/3 = the 32x32x16 form with a 4/3-slot ring, 0 = v1
+  // bf16: the LDS-DMA loop on v_mfma_f32_16x16x32_bf16.  (Ablation builds, -DS2S_ABLATE, additionally honour
+  // S2S_CONV_DMA = 1/3: the 32x32x16 form with a 4/3-slot ring, 0: the register-staged v1 loop.)
+#ifdef S2S_ABLATE
   static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
-  if (use_dma == 16) {
-    switch (id) {
-      case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
-      case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
-      case 2: return launch_dma16<4, 32, 128, 2, 2, 4>(a, s);
-      case 3: return launch_dma16<4, 32, 64, 2, 2, 4>(a, s);
-      case 4: return launch_dma16<16, 16, 128, 2, 2, 4>(a, s);
-      case 5: return launch_dma16<16, 16, 64, 4, 1, 4>(a, s);
-      case 6: return launch_dma16<8, 16, 128, 2, 2, 4>(a, s);
-      case 7: return launch_dma16<8, 16, 64, 2, 2, 4>(a, s);
-    }
-  }
-  if (use_dma) {
-    // the alignment the DMA path needs beyond the register-staged one: 16-B aligned pixel rows
+  if (use_dma != 16 && use_dma) {
     switch (id) {
       case 0: return use_dma == 3 ? launch_dma<8, 32, 128, 2, 2, 3>(a, s) : launch_dma<8, 32, 128, 2, 2, 4>(a, s);
       case 1: return use_dma == 3 ? launch_dma<8, 32, 64, 4, 1, 3>(a, s) : launch_dma<8, 32, 64, 4, 1, 4>(a, s);
@@ -1699,15 +1706,28 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
       case 7: return use_dma == 3 ? launch_dma<8, 16, 64, 2, 2, 3>(a, s) : launch_dma<8, 16, 64, 2, 2, 4>(a, s);
     }
   }
+  if (!use_dma) {
+    switch (id) {
+      case 0: return launch_cfg<bf16_t, 8, 32, 128, 2, 2>(a, s);
+      case 1: return launch_cfg<bf16_t, 8, 32, 64, 4, 1>(a, s);
+      case 2: return launch_cfg<bf16_t, 4, 32, 128, 2, 2>(a, s);
+      case 3: return launch_cfg<bf16_t, 4, 32, 64, 2, 2>(a, s);
+      case 4: return launch_cfg<bf16_t, 16, 16, 128, 2, 2>(a, s);
+      case 5: return launch_cfg<bf16_t, 16, 16, 64, 4, 1>(a, s);
+      case 6: return launch_cfg<bf16_t, 8, 16, 128, 2, 2>(a, s);
+      case 7: return launch_cfg<bf16_t, 8, 16, 64, 2, 2>(a, s);
+    }
+  }
+#endif
   switch (id) {
-    case 0: return launch_cfg<bf16_t, 8, 32, 128, 2, 2>(a, s);
-    case 1: return launch_cfg<bf16_t, 8, 32, 64, 4, 1>(a, s);
-    case 2: return launch_cfg<bf16_t, 4, 32, 128, 2, 2>(a, s);
-    case 3: return launch_cfg<bf16_t, 4, 32, 64, 2, 2>(a, s);
-    case 4: return launch_cfg<bf16_t, 16, 16, 128, 2, 2>(a, s);
-    case 5: return launch_cfg<bf16_t, 16, 16, 64, 4, 1>(a, s);
-    case 6: return launch_cfg<bf16_t, 8, 16, 128, 2, 2>(a, s);
-    case 7: return launch_cfg<bf16_t, 8, 16, 64, 2, 2>(a, s);
+    case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
+    case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
+    case 2: return launch_dma16<4, 32, 128, 2, 2, 4>(a, s);
+    case 3: return launch_dma16<4, 32, 64, 2, 2, 4>(a, s);
+    case 4: return launch_dma16<16, 16, 128, 2, 2, 4>(a, s);
+    case 5: return launch_dma16<16, 16, 64, 4, 1, 4>(a, s);
+    case 6: return launch_dma16<8, 16, 128, 2, 2, 4>(a, s);
+    case 7: return launch_dma16<8, 16, 64, 2, 2, 4>(a, s);
   }
   return S2S_ERR_SHAPE;
 }
@@ -1758,8 +1778,10 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
 extern "C" int s2s_conv3x3_ksplit(int dtype, int B, int H, int W, int Cout, int cin) {
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || cin <= 0) return S2S_ERR_SHAPE;
   if (dtype != S2S_BF16) return 1;
+#ifdef S2S_ABLATE
   static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
   if (use_dma != 16) return 1;
+#endif
   const TileCfg& c = kBf16Cfg[select_cfg(dtype, B, H, W, Cout)];
   const long base = cfg_blocks(c, B, H, W, Cout);
   const int nchunk = cdiv(cin, 32);
@@ -1796,7 +1818,9 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
   a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
   a.tilesX = a.tilesY = 0;
-  { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+  // S2S_CONV_DBG: 64 = clock probe, 128 = the earlier LDS slot key (both leave the results unchanged); the
+  // result-changing timing ablations (bits 1-32) exist only in -DS2S_ABLATE builds
+  { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return (e ? atoi(e) : 0) & S2S_DBG_MASK; }(); a.dbg = dbg; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   a.ksplit = (kwork && !stat_part) ? s2s_conv3x3_ksplit(dtype, B, H, W, Cout, c0 + c1) : 1;

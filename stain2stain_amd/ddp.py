@@ -108,6 +108,24 @@ class GradBucketer:
         n = (hi - lo) // self.world
         return lo + self.rank * n, lo + (self.rank + 1) * n
 
+    def closes(self, group_index: int) -> bool:
+        """True if marking ``group_index`` ready would launch at least one collective."""
+        return self._next < len(self.buckets) and self.buckets[self._next][0] <= group_index
+
+    def mark_ready_ordered(self, group_index: int, side: Optional["torch.cuda.Stream"]) -> None:
+        """``mark_ready`` for a step whose gradients are written on TWO streams: the current (compute) stream -- norm /
+        bias / linear-layer gradients -- and ``side`` -- the weight gradients (engine.run_on_side).  The collective of a
+        bucket that closes here is issued from ``side`` after ``side`` has been made to wait for everything enqueued on
+        the compute stream so far, so it is ordered behind both, whichever group closes the bucket (a group with no
+        side-stream work after its compute-stream kernels -- the head, the time MLP -- included)."""
+        if side is None or not self.enabled:
+            self.mark_ready(group_index)
+            return
+        if self.closes(group_index):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.mark_ready(group_index)
+
     def mark_ready(self, group_index: int) -> None:
         """Groups 0..group_index have their gradients written (in stream order): exchange complete buckets."""
         while self._next < len(self.buckets) and self.buckets[self._next][0] <= group_index:

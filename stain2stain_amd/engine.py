@@ -387,7 +387,7 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
                      g_head: Optional[torch.Tensor] = None):
     """Returns (dbottleneck, [dskip per level], dt_emb or None); all NHWC in the compute dtype.
     ``on_group_done()``: after the head, after every conv + BatchNorm layer (last Up block first, its second conv before
-    its first), then after the time path."""
+    its first), then after the time path (only when the decoder has one)."""
     if g_head is not None:      # head gradients already produced by the fused head+loss kernel
         g = g_head
     else:
@@ -411,9 +411,7 @@ def decoder_backward(dec, ctx: DecCtx, dv: Optional[torch.Tensor], grads: Dict[s
         if on_group_done is not None:
             on_group_done()
     dbott = g
-    if getattr(dec, "time_mlp", None) is None:
-        if on_group_done is not None:
-            on_group_done()
+    if getattr(dec, "time_mlp", None) is None:      # no time path, no parameter group for it (trainer._param_groups)
         return dbott, dskips, None
     # time path: tbias was broadcast-added to the bottleneck before the first up-sampling
     dtb = ops.pixel_sum(g)

@@ -73,14 +73,16 @@ def _L():
 # The weight-gradient kernels write tens of MB of fp32 partial slabs per launch.  Taking them from torch's caching
 # allocator ties them to the stream that happens to be current (the allocator pools per stream): a step that runs its
 # weight gradients on another stream than the previous one finds no cached block, falls through to hipMalloc and stalls
-# the queue for ~0.2 ms per launch.  One grow-only buffer per (device, tag) instead; every user of a tag issues its
-# launches on one stream at a time (the weight gradients of a step are serialised on the side stream, and joined before
-# the next step), so consecutive launches may share it.
+# the queue for ~0.2 ms per launch.  One grow-only buffer per (device, tag, stream) instead: launches on one stream are
+# serialised, so consecutive launches may share it, and a buffer is only ever replaced (grown) by the stream that uses
+# it -- the allocator returns the old block to that same stream's pool, where any re-use is ordered behind the launches
+# that still read it.  (Keyed by (device, tag) alone, a larger launch on the side stream could retire a block the compute
+# stream had allocated while the side stream's previous launch was still reading its slabs: ADVICE r2.)
 _WORKSPACE = {}
 
 
 def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream())
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < numel:
         buf = torch.empty((max(numel, 1 << 20),), dtype=torch.float32, device=device)
@@ -106,11 +108,13 @@ def profile_start(only=None) -> None:
 def cu_masked_stream(device, spec: str) -> torch.cuda.Stream:
     """A HIP stream confined to a subset of the compute units: ``spec`` = "K:M" enables CU i iff i % M < K (e.g. "3:4" =
     three quarters of the chip, spread evenly whatever the CU numbering).  For the weight-gradient side stream."""
-    import ctypes
     k, m = (int(v) for v in spec.split(":"))
     if not 0 < k <= m:
         raise ValueError("CU mask spec K:M needs 0 < K <= M")
     dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), k, m)
+    if key in _MASKED_STREAMS:
+        return _MASKED_STREAMS[key]
     n = torch.cuda.get_device_properties(dev).multi_processor_count
     words = (ctypes.c_uint32 * ((n + 31) // 32))()
     for i in range(n):
@@ -120,11 +124,18 @@ def cu_masked_stream(device, spec: str) -> torch.cuda.Stream:
     with torch.cuda.device(dev):
         _native.check(_L().s2s_stream_create_cu_mask(ctypes.addressof(words), len(words), ctypes.addressof(out)),
                       "stream_create_cu_mask")
+    # The hipStream_t lives as long as the process (one per (device, K, M), cached): torch's caching allocator keys the
+    # blocks that were allocated under `with torch.cuda.stream(side)` -- and their pending free-events -- by the raw
+    # stream handle and keeps them after the Python object is gone, so destroying the stream when its ExternalStream
+    # wrapper is collected leaves the allocator with a dangling handle that it touches again on a later free / at
+    # teardown (the round-2 exit-time segmentation fault of the GPU suite).  ExternalStream never owned the handle;
+    # nothing destroys it now, process teardown releases the queue.
     stream = torch.cuda.ExternalStream(out.value, device=dev)
-    import weakref
-    fin = weakref.finalize(stream, _L().s2s_stream_destroy, out.value)  # ExternalStream does not own the hipStream_t
-    fin.atexit = False            # not at interpreter exit: the HIP runtime may be gone by then (process teardown frees it)
+    _MASKED_STREAMS[key] = stream
     return stream
+
+
+_MASKED_STREAMS = {}
 
 
 def side_stream_for(device) -> Optional[torch.cuda.Stream]:

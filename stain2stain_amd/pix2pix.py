@@ -340,8 +340,8 @@ class Pix2PixGenerator(nn.Module):
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, ngf: int = 64, num_downs: int = 8):
         super().__init__()
-        if num_downs < 3:
-            raise ValueError("num_downs >= 3")
+        if num_downs < 2:                 # (2 = BASELINE.json configs[0]'s "2-level U-Net": outermost + innermost layer)
+            raise ValueError("num_downs >= 2")
         ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]
         self.in_channels, self.out_channels = in_channels, out_channels
         self.downs = nn.ModuleList([Conv4x4Stride2(8 if i == 0 else ch[i - 1], ch[i]) for i in range(num_downs)])
@@ -374,23 +374,41 @@ class Pix2PixGenerator(nn.Module):
 
 
 class PatchGANDiscriminator(nn.Module):
-    """70x70 PatchGAN: C64 - C128 - C256 (stride 2) - C512 - C1 (stride 1), LeakyReLU(0.2), InstanceNorm on the three
-    middle layers; input = cat(source, target or generated) along the channels."""
+    """PatchGAN: C(ndf) stride 2 with LeakyReLU(0.2), ``n_layers - 1`` more stride-2 layers and one stride-1 layer with
+    InstanceNorm + LeakyReLU (channels doubling up to 8 ndf), then the stride-1 logit layer; input = cat(source, target
+    or generated) along the channels.  ``n_layers = 3`` is the 70x70 PatchGAN C64 - C128 - C256 - C512 - C1 (layers
+    ``c1`` ... ``c5``, norms ``n2`` ... ``n4``); ``n_layers = 1`` is BASELINE.json configs[0]'s "1-layer PatchGAN"
+    (C64 - C128 - C1: ``c1``, ``c2`` / ``n2``, ``c3``)."""
 
-    def __init__(self, in_channels: int = 6, ndf: int = 64):
+    def __init__(self, in_channels: int = 6, ndf: int = 64, n_layers: int = 3):
         super().__init__()
+        if n_layers < 1:
+            raise ValueError("n_layers >= 1")
+        self.n_layers = n_layers
         self.c1 = Conv4x4Stride2(8, ndf)
-        self.c2, self.n2 = Conv4x4Stride2(ndf, 2 * ndf), InstanceNormLeakyReLU(2 * ndf)
-        self.c3, self.n3 = Conv4x4Stride2(2 * ndf, 4 * ndf), InstanceNormLeakyReLU(4 * ndf)
-        self.c4, self.n4 = Conv4x4Stride1(4 * ndf, 8 * ndf), InstanceNormLeakyReLU(8 * ndf)
-        self.c5 = Conv4x4Stride1(8 * ndf, 8)                        # one logit channel, padded to 8
+        kinds = ["s2"]
+        cin = ndf
+        for n in range(1, n_layers + 1):
+            cout = ndf * min(2 ** n, 8)
+            stride1 = n == n_layers
+            setattr(self, f"c{n + 1}", (Conv4x4Stride1 if stride1 else Conv4x4Stride2)(cin, cout))
+            setattr(self, f"n{n + 1}", InstanceNormLeakyReLU(cout))
+            kinds.append("s1" if stride1 else "s2")
+            cin = cout
+        setattr(self, f"c{n_layers + 2}", Conv4x4Stride1(cin, 8))      # one logit channel, padded to 8
+        kinds.append("s1")
+        self.layer_kinds = kinds                                        # kinds[k] of layer c{k+1}
+
+    def conv_layers(self):
+        """[(name, kind, module)] in forward order."""
+        return [(f"c{k + 1}", kind, getattr(self, f"c{k + 1}")) for k, kind in enumerate(self.layer_kinds)]
 
     def forward(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        K = len(self.layer_kinds)
         h = torch.nn.functional.leaky_relu(self.c1(_pad_channels(torch.cat([a, b], 1), 8)), 0.2)
-        h = self.n2(self.c2(h))
-        h = self.n3(self.c3(h))
-        h = self.n4(self.c4(h))
-        return self.c5(h)[:, :1].float()
+        for k in range(2, K):
+            h = getattr(self, f"n{k}")(getattr(self, f"c{k}")(h))
+        return getattr(self, f"c{K}")(h)[:, :1].float()
 
 
 def pix2pix_losses(G: nn.Module, D: nn.Module, src: torch.Tensor, tgt: torch.Tensor, lambda_l1: float = 100.0):

@@ -81,6 +81,30 @@ class FlatParams:
                            betas[1], eps, weight_decay, self.bucketer.grad_scale)
         self.bucketer.all_gather(self.p)
 
+    def state_dict(self) -> Dict:
+        """Adam state by parameter name.  Sharded optimiser: the moments are all-gathered first (a collective: every rank
+        calls), so the dump is complete on every rank."""
+        if self.bucketer.mode == "reduce_scatter" and self.bucketer.enabled and self.step_count > 0:
+            self.bucketer.all_gather(self.m)
+            self.bucketer.all_gather(self.v)
+        out = {"step": self.step_count, "exp_avg": {}, "exp_avg_sq": {}}
+        for name, (o, n) in self.slot.items():
+            shape = self.grads[name].shape
+            out["exp_avg"][name] = self.m[o:o + n].view(shape).clone()
+            out["exp_avg_sq"][name] = self.v[o:o + n].view(shape).clone()
+        return out
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if set(sd["exp_avg"]) != set(self.slot) or set(sd["exp_avg_sq"]) != set(self.slot):
+            raise ValueError("optimizer state does not match this network's parameters")
+        for name, (o, n) in self.slot.items():
+            for buf, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
+                t = sd[key][name]
+                if tuple(t.shape) != tuple(self.grads[name].shape):
+                    raise ValueError(f"optimizer state {name}: shape {tuple(t.shape)} != {tuple(self.grads[name].shape)}")
+                buf[o:o + n].copy_(t.reshape(-1))
+        self.step_count = int(sd["step"])
+
 
 @dataclass
 class _Layer:
@@ -211,9 +235,7 @@ class Pix2PixTrainer:
         self.n = n
         self.g_down = [_Layer(f"downs.{i}", "s2", m.weight, m.bias) for i, m in enumerate(G.downs)]
         self.g_up = [_Layer(f"ups.{j}", "t2", m.weight, m.bias) for j, m in enumerate(G.ups)]
-        self.d_layers = [_Layer("c1", "s2", D.c1.weight, D.c1.bias), _Layer("c2", "s2", D.c2.weight, D.c2.bias),
-                         _Layer("c3", "s2", D.c3.weight, D.c3.bias), _Layer("c4", "s1", D.c4.weight, D.c4.bias),
-                         _Layer("c5", "s1", D.c5.weight, D.c5.bias)]
+        self.d_layers = [_Layer(name, kind, m.weight, m.bias) for name, kind, m in D.conv_layers()]
 
         def group(l: _Layer):
             return [(l.name + ".weight", l.weight)] + ([(l.name + ".bias", l.bias)] if l.bias is not None else [])
@@ -232,14 +254,22 @@ class Pix2PixTrainer:
         self.overlap_wgrad = True
         self.last: Dict[str, torch.Tensor] = {}
 
+    def optimizer_state_dict(self) -> Dict:
+        """Both Adam states (by parameter name) + hyper-parameters; a collective with ``sharded_optimizer`` (FlatParams.state_dict)."""
+        return {"G": self.pG.state_dict(), "D": self.pD.state_dict(),
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> None:
+        self.pG.load_state_dict(sd["G"])
+        self.pD.load_state_dict(sd["D"])
+        h = sd.get("hyper", {})
+        self.lr, self.betas = h.get("lr", self.lr), tuple(h.get("betas", self.betas))
+        self.eps, self.wd = h.get("eps", self.eps), h.get("weight_decay", self.wd)
+
     def _mark(self, fp: FlatParams, group: int) -> None:
-        """Group ``group`` of ``fp`` has its gradients enqueued (weight gradient on the side stream, which was forked
-        after the layer's other gradients): exchange the buckets it closes, ordered behind the side stream."""
-        if engine.side_stream is not None and fp.bucketer.enabled:
-            with torch.cuda.stream(engine.side_stream):
-                fp.bucketer.mark_ready(group)
-        else:
-            fp.bucketer.mark_ready(group)
+        """Group ``group`` of ``fp`` has its gradients enqueued (bias gradients on the compute stream, the weight gradient
+        on the side stream): exchange the buckets it closes, ordered behind both streams."""
+        fp.bucketer.mark_ready_ordered(group, engine.side_stream)
 
     def _join(self) -> None:
         engine.join_side()
@@ -329,49 +359,52 @@ class Pix2PixTrainer:
     # discriminator
     # ------------------------------------------------------------------------------------------------------------
     def d_forward(self, d_in: torch.Tensor):
-        """d_in [N,H,W,8] = [src | target-or-fake | 0 0] -> (logits [N,H/8-2,W/8-2,8] (channel 0), saved tensors)."""
-        c1, c2, c3, c4, c5 = self.d_layers
-        a1, xs1 = _conv_s2_fwd(c1, d_in, act=True, slope=LRELU)
-        r2, xs2 = _conv_s2_fwd(c2, a1)
-        a2 = torch.empty_like(r2)
-        s2 = ops.instnorm_lrelu_fwd2(r2, LRELU, a2)
-        r3, xs3 = _conv_s2_fwd(c3, a2)
-        a3 = torch.empty_like(r3)
-        s3 = ops.instnorm_lrelu_fwd2(r3, LRELU, a3)
-        r4 = ops.convkxk(a3, c4.wf, c4.bias.detach(), c4.conv_out, 4, 1)
-        a4 = torch.empty_like(r4)
-        s4 = ops.instnorm_lrelu_fwd2(r4, LRELU, a4)
-        z = ops.convkxk(a4, c5.wf, c5.bias.detach(), c5.conv_out, 4, 1)
-        return z, (xs1, a1, xs2, r2, s2, xs3, r3, s3, a3, r4, s4, a4)
+        """d_in [N,H,W,8] = [src | target-or-fake | 0 0] -> (logits [N,h,w,8] (channel 0), saved): ``saved[k]`` =
+        (what layer k's weight gradient reads, conv output ahead of the norm or None, norm statistics or None,
+        activation or None) for the layers c1 ... cK of the PatchGAN (first: LeakyReLU without a norm; last: logits)."""
+        L, saved, x = self.d_layers, [], d_in
+        for k, l in enumerate(L):
+            if k == len(L) - 1:
+                z = ops.convkxk(x, l.wf, l.bias.detach(), l.conv_out, 4, 1)
+                saved.append((x, None, None, None))
+                return z, saved
+            if k == 0:
+                a, xs = _conv_s2_fwd(l, x, act=True, slope=LRELU)
+                saved.append((xs, None, None, a))
+            else:
+                if l.kind == "s2":
+                    r, xs = _conv_s2_fwd(l, x)
+                else:
+                    r, xs = ops.convkxk(x, l.wf, l.bias.detach(), l.conv_out, 4, 1), x
+                a = torch.empty_like(r)
+                st = ops.instnorm_lrelu_fwd2(r, LRELU, a)
+                saved.append((xs, r, st, a))
+            x = a
 
     def d_backward(self, saved, dz: torch.Tensor, want_w: bool, need_input_grad: bool):
         """want_w: form the discriminator's weight gradients (D update) -- the generator update passes False and only
         pulls the data gradient through the frozen discriminator.  Returns d(d_in) or None."""
-        c1, c2, c3, c4, c5 = self.d_layers
-        xs1, a1, xs2, r2, s2, xs3, r3, s3, a3, r4, s4, a4 = saved
+        L = self.d_layers
         gr, bk = self.pD.grads, self.pD.bucketer
         if want_w:
             bk.start_step()
-            ops.channel_sum_into(dz, gr["c5.bias"])
-        g = _conv_s1_bwd(c5, dz, a4, gr["c5.weight"], want_w)
-        if want_w:
-            self._mark(self.pD, 0)
-        g = ops.instnorm_lrelu_bwd2(g, None, r4, s4, LRELU)
-        g = _conv_s1_bwd(c4, g, a3, gr["c4.weight"], want_w)
-        if want_w:
-            self._mark(self.pD, 1)
-        g = ops.instnorm_lrelu_bwd2(g, None, r3, s3, LRELU)
-        g = _conv_s2_bwd(c3, g, xs3, gr["c3.weight"], True, want_w)
-        if want_w:
-            self._mark(self.pD, 2)
-        g = ops.instnorm_lrelu_bwd2(g, None, r2, s2, LRELU)
-        g = _conv_s2_bwd(c2, g, xs2, gr["c2.weight"], True, want_w)
-        if want_w:
-            self._mark(self.pD, 3)
-        g = ops.p2p_act_bwd(g, None, a1, LRELU, gr["c1.bias"] if want_w else None)
-        g = _conv_s2_bwd(c1, g, xs1, gr["c1.weight"], need_input_grad, want_w)
-        if want_w:
-            self._mark(self.pD, 4)
+        g = dz
+        for grp, k in enumerate(range(len(L) - 1, -1, -1)):
+            l = L[k]
+            xs, r, st, a = saved[k]
+            if k == len(L) - 1:
+                if want_w:
+                    ops.channel_sum_into(g, gr[l.name + ".bias"])
+            elif k == 0:
+                g = ops.p2p_act_bwd(g, None, a, LRELU, gr[l.name + ".bias"] if want_w else None)
+            else:
+                g = ops.instnorm_lrelu_bwd2(g, None, r, st, LRELU)
+            if l.kind == "s1":
+                g = _conv_s1_bwd(l, g, xs, gr[l.name + ".weight"], want_w)
+            else:
+                g = _conv_s2_bwd(l, g, xs, gr[l.name + ".weight"], k > 0 or need_input_grad, want_w)
+            if want_w:
+                self._mark(self.pD, grp)
         return g
 
     # ------------------------------------------------------------------------------------------------------------
@@ -406,7 +439,7 @@ class Pix2PixTrainer:
             zg, saved_g = self.d_forward(d_in[B:])                          # through the UPDATED discriminator
         else:
             self.pD.bucketer.wait_all()
-            zg, saved_g = z[B:], tuple(self._second_half(t, B) for t in saved)
+            zg, saved_g = z[B:], [tuple(None if t is None else self._second_half(t, B) for t in lay) for lay in saved]
         # ---- generator update ----
         _, dzg = ops.p2p_bce_logits(zg, B, 1.0 / (B * npatch), 0.0, out=losses[2:4])
         gd = self.d_backward(saved_g, dzg, want_w=False, need_input_grad=True)

@@ -208,14 +208,11 @@ class CFMTrainer:
         return loss, dctx.v
 
     def _group_done(self) -> None:
-        """The next parameter group (layer, in _param_groups order) has its gradients enqueued: the layer's BatchNorm
-        gradients on the compute stream, its weight gradient on the side stream, which was forked after them -- so the
-        bucket's collective is ordered behind the side stream."""
-        if self._side is not None and self.overlap_wgrad and self.bucketer.enabled:
-            with torch.cuda.stream(self._side):
-                self.bucketer.mark_ready(self._group)
-        else:
-            self.bucketer.mark_ready(self._group)
+        """The next parameter group (layer, in _param_groups order) has its gradients enqueued: BatchNorm / bias / linear
+        gradients on the compute stream, the conv weight gradient on the side stream.  A bucket that closes here is
+        exchanged behind BOTH streams (GradBucketer.mark_ready_ordered): the head and the time-MLP groups have no
+        side-stream fork after their compute-stream kernels, so ordering behind the side stream alone is not enough."""
+        self.bucketer.mark_ready_ordered(self._group, self._side if self.overlap_wgrad else None)
         self._group += 1
 
     def optimizer_step(self) -> None:
@@ -234,6 +231,12 @@ class CFMTrainer:
     # optimiser state in torch.optim.Adam's own layout, so a run can move between this trainer and the
     # reference's Lightning loop (checkpoint["optimizer_states"][0], parameters in net.parameters() order)
     def optimizer_state_dict(self) -> Dict:
+        """With ``sharded_optimizer`` a rank's Adam moments are current only on its own 1/world of every bucket: they are
+        all-gathered first, so the dump is the full state on every rank (a COLLECTIVE in that mode: every rank calls it,
+        as Lightning's checkpoint hook does)."""
+        if self.bucketer.mode == "reduce_scatter" and self.bucketer.enabled and self.step_count > 0:
+            self.bucketer.all_gather(self.flat_m)
+            self.bucketer.all_gather(self.flat_v)
         state = {}
         for i, p in enumerate(self.net.parameters()):
             o, n = self._slot[id(p)]

@@ -47,8 +47,11 @@ def _worker(rank, world, port, q):
         ok = False
     except RuntimeError:
         pass
+    closing = []
     for g in range(len(sizes)):
-        bk.mark_ready(g)
+        closing.append(bk.closes(g))
+        bk.mark_ready_ordered(g, None)          # (no side stream on CPU: the plain mark_ready)
+    ok = ok and closing == [False, True, False, False, True] and not bk.closes(len(sizes) - 1)
     bk.wait_all()
     expect = torch.arange(sum(sizes), dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = ok and torch.equal(flat, expect) and abs(bk.grad_scale - 1.0 / world) < 1e-12

@@ -15,8 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = [{"S2S_WGRAD_KH": "1"}, {"S2S_WGRAD_KH": "2"}, {"S2S_CONV_XCD": "0", "S2S_WGRAD_XCD": "0"},
             {"S2S_WGRAD_DMA": "0"}, {"S2S_WGRAD_MFMA": "16"}]
-# (S2S_CONV_DMA=1/3/0, the earlier forms of the forward loop kept for ablations, take BatchNorm's partial sums from the
-#  fp32 accumulators rather than from the stored bf16 values and have no split-K form: not held to these tests.)
+# (The earlier forms of the forward loop, S2S_CONV_DMA=1/3/0, and the result-changing S2S_CONV_DBG timing bits are NOT in
+#  the product library any more: they are compiled only with -DS2S_ABLATE into libstain2stain_hip_ablate.so, which
+#  scripts/ load; tests/test_native_cpu.py checks that the shipped sources read no such switch outside that guard.)
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))

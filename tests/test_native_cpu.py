@@ -95,3 +95,47 @@ def test_unloadable_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_native, "_lib", None)
     with pytest.raises(RuntimeError, match="cannot load"):
         _native.lib()
+
+
+def test_product_library_has_no_result_changing_switches():
+    """the timing ablations that produce wrong results (S2S_CONV_DBG bits 1-32) and the superseded,
+    untested forward loops (S2S_CONV_DMA) must not be reachable in the shipped library through an environment variable.
+    Preprocess every source WITHOUT -DS2S_ABLATE (comments stripped, #ifdef S2S_ABLATE blocks dropped) and look at what
+    is left: no S2S_CONV_DMA read at all, and the S2S_CONV_DBG read masked to the result-preserving bits."""
+    import re
+    from stain2stain_amd import _native
+
+    def product_text(path):
+        out, skip = [], 0
+        for line in open(path).read().splitlines():
+            st = line.strip()
+            if skip:
+                if st.startswith("#if"):
+                    skip += 1
+                elif st.startswith("#else") and skip == 1:
+                    skip = 0
+                elif st.startswith("#endif"):
+                    skip -= 1
+                continue
+            if st.startswith("#ifdef S2S_ABLATE"):
+                skip = 1
+                continue
+            out.append(re.sub(r"//.*", "", line))
+        return "\n".join(out)
+
+    envs = {}
+    for src in _native.SOURCES:
+        text = product_text(os.path.join(_native.CSRC, src))
+        for name in re.findall(r'getenv\("(S2S_\w+)"\)', text):
+            envs.setdefault(name, []).append(src)
+        if "S2S_CONV_DBG" in text:
+            assert re.search(r'getenv\("S2S_CONV_DBG"\).*& S2S_DBG_MASK', text), src
+            assert re.search(r"#define S2S_DBG_MASK \(64 \| 128\)", text), src
+        assert not re.search(r"a\.dbg & (1|2|4|8|16|32)\b(?!\d)", re.sub(r"S2S_ABL\([^)]*\)", "", text)), src
+    assert "S2S_CONV_DMA" not in envs, envs.get("S2S_CONV_DMA")
+    # what remains is result-preserving (tile choice, workgroup order, split counts, equivalent kernels): each is either
+    # exercised by tests/test_env_variants_gpu.py or changes launch geometry only
+    allowed = {"S2S_CONV_DBG", "S2S_CONV_CFG", "S2S_CONV_XCD", "S2S_FLAT_NS", "S2S_WGRAD_XCD", "S2S_WGRAD_KH", "S2S_WGRAD_MFMA",
+               "S2S_WGRAD_BLOCKS", "S2S_WGRAD_CAP", "S2S_WGRAD_DMA", "S2S_STEM_WGRAD_BLOCKS", "S2S_HEAD_LANES",
+               "S2S_BN_DBIAS_SUM", "S2S_BN_REV", "S2S_UP_BWD_WIN"}
+    assert set(envs) <= allowed, set(envs) - allowed

@@ -27,19 +27,19 @@ def test_train_steps_match_reference(name, golden_tiny, golden_odd3):
     while f"step{steps}/x0" in G:
         steps += 1
     batches = [(G[f"step{s}/x0"], G[f"step{s}/x1"], G[f"step{s}/t"]) for s in range(steps)]
-    P_cur = {k: v.clone() for k, v in P.items()}
+    # the full multi-step run (Adam moments carried across steps): EVERY step's velocity, loss and gradients against the
+    # reference's -- step 1 runs on the oracle's own post-Adam parameters, so its comparison also covers the update
+    P_fin, hist = O.train_steps(P, batches, lr=1e-4, weight_decay=1e-5)
+    assert len(hist) == steps and (steps >= 2 or name != "tiny")      # (odd3 holds one step)
     for s in range(steps):
-        P_next, hist = O.train_steps(P_cur, [batches[s]], lr=1e-4, weight_decay=1e-5) if s == 0 else (None, None)
-        if s > 0:
-            break
-        assert relerr(hist[0]["v"], G[f"step{s}/v"]) < FWD_TOL
-        assert relerr(hist[0]["loss"], G[f"step{s}/loss"]) < FWD_TOL
+        # (later steps inherit the ~1e-6 parameter differences of the steps before them)
+        ftol, gmul = (FWD_TOL, 1.0) if s == 0 else (20 * FWD_TOL, 5.0)
+        assert relerr(hist[s]["v"], G[f"step{s}/v"]) < ftol, s
+        assert relerr(hist[s]["loss"], G[f"step{s}/loss"]) < ftol, s
         gref = sub(G, f"step{s}/grad/")
         gscale = max(float(v.abs().max()) for v in gref.values())
-        for k, g in hist[0]["grads"].items():
-            assert _grad_ok(g, gref[k], 1e-3 * gscale), k
-    # full multi-step run (Adam moments carried across steps)
-    P_fin, hist = O.train_steps(P, batches, lr=1e-4, weight_decay=1e-5)
+        for k, g in hist[s]["grads"].items():
+            assert float((g - gref[k]).abs().max()) <= gmul * GRAD_TOL * max(float(gref[k].abs().max()), 1e-3 * gscale), (s, k)
     last = sub(G, f"step{steps - 1}/after/")
     for k, v in last.items():
         if k.endswith("num_batches_tracked"):

@@ -200,15 +200,15 @@ def test_instnorm_second_output_and_second_gradient():
 # ----------------------------------------------------------------------------------------------------------------------
 # the two networks and the step
 # ----------------------------------------------------------------------------------------------------------------------
-def _build(ngf, ndf, num_downs, seed, bf16_weights):
+def _build(ngf, ndf, num_downs, seed, bf16_weights, n_layers=3):
     from oracle import pix2pix_oracle as O
     from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator
     torch.manual_seed(seed)
-    G, D = Pix2PixGenerator(ngf=ngf, num_downs=num_downs), PatchGANDiscriminator(ndf=ndf)
+    G, D = Pix2PixGenerator(ngf=ngf, num_downs=num_downs), PatchGANDiscriminator(ndf=ndf, n_layers=n_layers)
     rb = (lambda t: t.to(torch.bfloat16).float()) if bf16_weights else (lambda t: t.clone())
     sd_g, sd_d = {k: rb(v) for k, v in G.state_dict().items()}, {k: rb(v) for k, v in D.state_dict().items()}
     G.load_state_dict(sd_g); D.load_state_dict(sd_d)
-    Go, Do = O.OracleGenerator(ngf=ngf, num_downs=num_downs), O.OracleDiscriminator(ndf=ndf)
+    Go, Do = O.OracleGenerator(ngf=ngf, num_downs=num_downs), O.OracleDiscriminator(ndf=ndf, n_layers=n_layers)
     Go.load_state_dict(sd_g); Do.load_state_dict(sd_d)
     return G.to(DEV), D.to(DEV), Go, Do
 
@@ -281,6 +281,34 @@ def test_fp32_mode_matches_the_oracle_to_1e3():
         worst = max(worst, err / max(float(r.abs().max()), 1e-3 * scale))
         assert err <= bound, (k, err, bound)
     print(f"fp32 mode: worst gradient error {worst:.2e} (bound {TOL})")
+
+
+def test_baseline_config0_literal_form_2_level_unet_1_layer_patchgan():
+    """BASELINE.json configs[0] as worded: 64x64x3 tiles, 2-level U-Net generator + 1-layer PatchGAN, batch 4, fp32
+    (the reference has no such model, SURVEY F1: the oracle is the torch-layer restatement).  Output, losses, every
+    gradient at 1e-3, and two G + D Adam steps against torch.optim.Adam on the oracle."""
+    from stain2stain_amd import Pix2PixTrainer
+    from stain2stain_amd.pix2pix import pix2pix_step
+    G, D, Go, Do = _build(16, 16, 2, 1984, bf16_weights=False, n_layers=1)
+    assert len(G.downs) == 2 and [k for _, k, _ in D.conv_layers()] == ["s2", "s1", "s1"]
+    src, tgt = _screened_batch(Go, Do, (4, 3, 64, 64), 1984)
+    fake_o, ld_o, lg_o, gref = _oracle_eval(Go, Do, src, tgt, torch.float64)
+    tr = Pix2PixTrainer(G, D, precision="fp32", lr=2e-4)
+    losses, fake = tr.losses_and_grads(src.to(DEV), tgt.to(DEV), update=False, want_fake=True)
+    ld, lg = tr.loss_values(losses)
+    assert relerr(fake, fake_o) < TOL and abs(ld - ld_o) < TOL * abs(ld_o) and abs(lg - lg_o) < TOL * abs(lg_o)
+    got = _engine_grads(tr)
+    for net in ("G.", "D."):
+        scale = max(float(v.abs().max()) for k, v in gref.items() if k.startswith(net))
+        for k, r in gref.items():
+            if k.startswith(net):
+                assert float((got[k] - r).abs().max()) <= TOL * max(float(r.abs().max()), 1e-3 * scale), k
+    og = torch.optim.Adam(Go.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(Do.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    for _ in range(2):
+        ld_o, lg_o = pix2pix_step(Go, Do, og, od, src, tgt)
+        ld, lg = tr.loss_values(tr.step(src.to(DEV), tgt.to(DEV)))
+        assert abs(ld - float(ld_o)) < 2e-3 * abs(float(ld_o)) and abs(lg - float(lg_o)) < 2e-3 * abs(float(lg_o))
 
 
 def test_bf16_mode_tracks_the_oracle():

@@ -86,12 +86,45 @@ def _rank_main(rank, world, port, out_dir):
         tr = CFMTrainer(net, lr=LR, weight_decay=1e-5, **kw)
         assert tr.bucketer.enabled and tr.bucketer.world == world
         res[name] = _cfm_steps(tr, net, x0[lo:hi], x1[lo:hi], t[:, lo:hi])
+        if name in ("ddp", "sharded"):
+            # checkpoint -> fresh trainer -> one more step (a sharded rank's Adam moments are only current on
+            # its own shards; the dump must gather them) against the original trainer simply continuing
+            t3 = torch.rand(world * PER_RANK, generator=torch.Generator().manual_seed(7))[lo:hi]
+            sd = tr.optimizer_state_dict()              # every rank calls: a collective in sharded mode
+            weights = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+            net2 = _unet(300 + rank)
+            tr2 = CFMTrainer(net2, lr=LR, weight_decay=1e-5, **kw)
+            net2.load_state_dict(weights)
+            tr2.load_optimizer_state_dict(sd)
+            for trx, key in ((tr, "continued"), (tr2, "resumed")):
+                trx.forward_backward(x0[lo:hi].cuda(), x1[lo:hi].cuda(), t3.cuda(), want_v=False)
+                trx.optimizer_step()
+                torch.cuda.synchronize()
+                res[name][key] = trx.flat_p.cpu()
+            res[name]["moments_nonzero"] = bool(all(float(s["exp_avg_sq"].abs().max()) > 0 for s in sd["state"].values()))
     G, D = _p2p_nets(200 + rank)
     p2p = Pix2PixTrainer(G, D, precision="fp32", sync_loss=False)
     src, tgt = x0[:4][2 * rank: 2 * rank + 2], x1[:4][2 * rank: 2 * rank + 2]
     losses = p2p.step(src.cuda(), tgt.cuda())
     torch.cuda.synchronize()
     res["p2p"] = {"pG": p2p.pG.p.cpu(), "pD": p2p.pD.p.cpu(), "losses": losses.cpu()}
+    # the same for the pix2pix trainer with the sharded optimiser: step, dump, load into a fresh trainer, step both
+    G, D = _p2p_nets(200 + rank)
+    sh = Pix2PixTrainer(G, D, precision="fp32", sync_loss=False, sharded_optimizer=True)
+    sh.step(src.cuda(), tgt.cuda())
+    torch.cuda.synchronize()
+    res["p2p"]["sharded_pG"] = sh.pG.p.cpu()
+    sd = sh.optimizer_state_dict()
+    G2, D2 = _p2p_nets(400 + rank)
+    sh2 = Pix2PixTrainer(G2, D2, precision="fp32", sync_loss=False, sharded_optimizer=True)
+    G2.load_state_dict({k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+    D2.load_state_dict({k: v.detach().cpu().clone() for k, v in D.state_dict().items()})
+    sh2.packG.repack(); sh2.packD.repack()
+    sh2.load_optimizer_state_dict(sd)
+    for trx, key in ((sh, "continued"), (sh2, "resumed")):
+        trx.step(tgt.cuda(), src.cuda())
+        torch.cuda.synchronize()
+        res["p2p"][key] = (trx.pG.p.cpu(), trx.pD.p.cpu())
     torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -118,6 +151,21 @@ def test_replicas_stay_bit_equal(ranks):
     # reduce-scatter + Adam on 1/world of every bucket + all-gather: the same parameters as all-reduce + full Adam
     assert torch.equal(ranks[0]["sharded"]["param"], ranks[0]["ddp"]["param"])
     assert ranks[0]["sharded"]["loss"] == ranks[0]["ddp"]["loss"]
+
+
+def test_checkpointed_optimizer_state_resumes_bit_equal(ranks):
+    """Dump -> fresh trainer -> load -> one more step equals the original trainer continuing, in both exchange modes
+    (the sharded dump gathers the moments of the shards the other rank owns), and both modes agree with each other."""
+    for r in (0, 1):
+        for name in ("ddp", "sharded"):
+            assert ranks[r][name]["moments_nonzero"], name
+            assert torch.equal(ranks[r][name]["resumed"], ranks[r][name]["continued"]), (r, name)
+        assert torch.equal(ranks[r]["sharded"]["continued"], ranks[r]["ddp"]["continued"])
+        for k in (0, 1):
+            assert torch.equal(ranks[r]["p2p"]["resumed"][k], ranks[r]["p2p"]["continued"][k]), (r, k)
+    assert torch.equal(ranks[0]["sharded"]["resumed"], ranks[1]["sharded"]["resumed"])
+    assert torch.equal(ranks[0]["p2p"]["sharded_pG"], ranks[0]["p2p"]["pG"])       # sharded == all-reduce, pix2pix too
+    assert torch.equal(ranks[0]["p2p"]["resumed"][0], ranks[1]["p2p"]["resumed"][0])
 
 
 def test_allreduce_is_the_mean_of_the_rank_gradients(ranks):
