@@ -178,6 +178,10 @@ int s2s_euler_tick(float* t, int n, const float* table, int* counter, void* stre
 /* torch.optim.Adam step over a flat fp32 buffer (configs/model/*.yaml:3-7) */
 int s2s_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, void* stream);
+/* the same step with its scalars in DEVICE memory, hyper[8] = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^step,
+ * sqrt(1 - beta2^step), grad_scale}: the launch a hipGraph-captured training step replays while the host refreshes the
+ * eight floats (Lightning's optimizer.step() / scheduler surface, conditional_flow_matching.py:112-131) */
+int s2s_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, void* stream);
 long s2s_pack_conv3x3_fwd_elems(int Cout, int Cin);
 long s2s_pack_conv3x3_dgrad_elems(int Cout, int Cin);
 int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, void* stream);

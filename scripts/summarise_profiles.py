@@ -83,9 +83,13 @@ if os.path.exists(f"{src}/p2p_pmc_fetch/f_counter_collection.csv"):
         if not f or not w or not n:
             continue
         fk, wk = sum(f) / len(f), sum(w) / len(w)
-        out[label] = {"launches_sampled": len(f), "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024),
+        out[label] = {"launches_sampled": len(f), "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
+                      "hbm_bytes_per_launch_corrected": int((2 * fk + wk) * 1024),
                       "avg_launch_us": round(tot / n / 1e3, 2),
                       "hbm_gb_per_s_from_counters": round((2 * fk + wk) * 1024 / (tot / n), 1)}
     json.dump(out, open(f"profiles/{tag}_pix2pix_hbm_rates.json", "w"), indent=1)
+    # what bench.py's pix2pix.roofline.traffic reads
+    json.dump(out, open(f"profiles/{tag}_pix2pix_hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open("profiles/pix2pix_hbm_traffic_current.json", "w"), indent=1)
     for k, v in out.items():
         print(f"pix2pix {k:52s} {v['hbm_bytes_per_launch_corrected']/1e6:9.1f} MB/launch {v['hbm_gb_per_s_from_counters']:8.1f} GB/s")

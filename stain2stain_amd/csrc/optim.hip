@@ -12,9 +12,9 @@
 
 namespace {
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                          float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                          float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float pi = p[i];
@@ -27,6 +27,20 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     m[i] = mi;
     v[i] = vi;
   }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
+  adam_body(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+}
+
+// The same step with its scalars read from DEVICE memory: hyper[8] = {lr, beta1, beta2, eps, weight_decay, bc1,
+// sqrt(bc2), grad_scale}.  A hipGraph-captured training step replays this launch unchanged while the host refreshes the
+// eight floats (step count -> bias corrections, scheduler -> lr) before every replay.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, const float* __restrict__ hyper) {
+  adam_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]);
 }
 
 template <typename T>
@@ -164,6 +178,14 @@ extern "C" int s2s_adam_step(float* p, const float* g, float* m, float* v, long 
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, void* stream) {
+  if (!p || !g || !m || !v || !hyper) return S2S_ERR_NULL;
+  if (n <= 0) return S2S_ERR_SHAPE;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

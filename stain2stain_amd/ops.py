@@ -694,6 +694,50 @@ def adam_step_(p, g, m, v, step: int, lr: float, beta1: float = 0.9, beta2: floa
                   "adam_step")
 
 
+def adam_hyper(step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+               grad_scale: float) -> list:
+    """The eight floats ``adam_step_dev_`` reads, formed exactly as s2s_adam_step forms its kernel arguments."""
+    import math
+    import struct
+    f32 = lambda x: struct.unpack("f", struct.pack("f", float(x)))[0]      # the C entry point takes beta as `float`
+    bc1 = 1.0 - math.pow(f32(beta1), float(step))
+    bc2 = 1.0 - math.pow(f32(beta2), float(step))
+    return [float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, math.sqrt(bc2), float(grad_scale)]
+
+
+class AdamHyperRing:
+    """The eight Adam scalars of a captured training step: ``dev`` is what the replayed kernel reads; ``push`` refreshes
+    it from the host in stream order without a synchronisation (pinned staging slots, each re-used only after the copy
+    that read it has completed -- the host runs ahead of the GPU by a step or two, never by the ring's length without
+    this check stalling it)."""
+    SLOTS = 16
+
+    def __init__(self, device):
+        self.dev = torch.zeros(8, dtype=torch.float32, device=device)
+        self._host = torch.empty((self.SLOTS, 8), dtype=torch.float32).pin_memory()
+        self._done = [None] * self.SLOTS
+        self._i = 0
+
+    def push(self, values) -> None:
+        i = self._i
+        self._i = (i + 1) % self.SLOTS
+        if self._done[i] is not None:
+            self._done[i].synchronize()
+        self._host[i] = torch.tensor(values, dtype=torch.float32)
+        self.dev.copy_(self._host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._done[i] = ev
+
+
+def adam_step_dev_(p, g, m, v, hyper: torch.Tensor) -> None:
+    """Adam with its scalars in a device float[8] (``adam_hyper``): what a captured training step replays."""
+    if hyper.numel() != 8:
+        raise RuntimeError("stain2stain_amd: adam hyper-parameter buffer must hold 8 floats")
+    _native.check(_L().s2s_adam_step_dev(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), _f32(hyper), _stream()),
+                  "adam_step_dev")
+
+
 @_timed("pack_conv3x3")
 def pack_conv3x3(w_oihw: torch.Tensor, dtype: torch.dtype, want_dgrad: bool = True, out=None):
     cout, cin = w_oihw.shape[:2]

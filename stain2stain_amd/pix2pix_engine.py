@@ -73,12 +73,19 @@ class FlatParams:
         self.step_count = 0
         broadcast_from_rank0([self.p], process_group)
 
-    def adam(self, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float) -> None:
+    def adam(self, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float,
+             hyper_dev: Optional[torch.Tensor] = None) -> None:
+        """``hyper_dev``: the Adam scalars in device memory (a captured step; the caller advances ``step_count`` and
+        refreshes them before each replay) instead of kernel arguments."""
         self.bucketer.wait_all()
-        self.step_count += 1
+        if hyper_dev is None:
+            self.step_count += 1
         for lo, hi in self.bucketer.shards():              # everything, or this rank's slices in sharded mode
-            ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.step_count, lr, betas[0],
-                           betas[1], eps, weight_decay, self.bucketer.grad_scale)
+            if hyper_dev is None:
+                ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.step_count, lr, betas[0],
+                               betas[1], eps, weight_decay, self.bucketer.grad_scale)
+            else:
+                ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], hyper_dev)
         self.bucketer.all_gather(self.p)
 
     def state_dict(self) -> Dict:
@@ -221,7 +228,10 @@ class Pix2PixTrainer:
     def __init__(self, G: Pix2PixGenerator, D: PatchGANDiscriminator, lr: float = 2e-4,
                  betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  lambda_l1: float = 100.0, precision: str = "bf16", bucket_mb: float = 4.0, process_group=None,
-                 sync_loss: bool = True, max_bucket_mb: float = 16.0, sharded_optimizer: bool = False):
+                 sync_loss: bool = True, max_bucket_mb: float = 16.0, sharded_optimizer: bool = False,
+                 graph: bool = False):
+        """``graph``: ``step()`` replays one captured hipGraph per G + D step (~200 launches on two streams); the first
+        step of a batch shape runs eagerly, the second captures; bit-equal to the eager step (see CFMTrainer)."""
         dev = next(G.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("stain2stain_amd: Pix2PixTrainer needs the networks on a GPU (HIP-only implementation)")
@@ -253,6 +263,12 @@ class Pix2PixTrainer:
         self._side = ops.side_stream_for(dev)
         self.overlap_wgrad = True
         self.last: Dict[str, torch.Tensor] = {}
+        self.graph = graph
+        self._captured, self._warm_key = None, None
+        self._hyper = ops.AdamHyperRing(dev) if graph else None
+        if graph and self.pG.bucketer.enabled and dist.get_backend(process_group) != "nccl":
+            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
+                               "collectives can be captured")
 
     def optimizer_state_dict(self) -> Dict:
         """Both Adam states (by parameter name) + hyper-parameters; a collective with ``sharded_optimizer`` (FlatParams.state_dict)."""
@@ -410,7 +426,8 @@ class Pix2PixTrainer:
     # ------------------------------------------------------------------------------------------------------------
     # the step
     # ------------------------------------------------------------------------------------------------------------
-    def losses_and_grads(self, src: torch.Tensor, tgt: torch.Tensor, update: bool = True, want_fake: bool = False):
+    def losses_and_grads(self, src: torch.Tensor, tgt: torch.Tensor, update: bool = True, want_fake: bool = False,
+                         hyper_dev: Optional[torch.Tensor] = None):
         """One G + D evaluation.  ``update=True`` is the training step (D is updated before the generator's pass through
         it, as in pix2pix_step); ``update=False`` leaves both networks untouched and evaluates the two losses and both
         gradient sets at the CURRENT parameters (what ``(loss_D + loss_G).backward()`` of pix2pix_losses yields), for the
@@ -434,7 +451,7 @@ class Pix2PixTrainer:
         self.d_backward(saved, dz, want_w=True, need_input_grad=False)
         self._join()
         if update:
-            self.pD.adam(self.lr, self.betas, self.eps, self.wd)
+            self.pD.adam(self.lr, self.betas, self.eps, self.wd, hyper_dev)
             self.packD.repack()
             zg, saved_g = self.d_forward(d_in[B:])                          # through the UPDATED discriminator
         else:
@@ -448,7 +465,7 @@ class Pix2PixTrainer:
         self.g_backward(gctx, dh)
         self._join()
         if update:
-            self.pG.adam(self.lr, self.betas, self.eps, self.wd)
+            self.pG.adam(self.lr, self.betas, self.eps, self.wd, hyper_dev)
             self.packG.repack()
         else:
             self.pG.bucketer.wait_all()
@@ -468,13 +485,42 @@ class Pix2PixTrainer:
         """One training step on this rank's shard of the global batch (the reference shards a batch as
         ``batch_size // world_size`` per rank, src/data/paired_data_module.py:273-278); returns the ``losses`` vector
         (rank means when ``sync_loss``), still on the device."""
-        losses, _ = self.losses_and_grads(src, tgt, update=True)
+        if self.graph and ops._PROFILE is None:
+            return self._step_graphed(src, tgt)
+        return self._step_body(src, tgt, None)
+
+    def _step_body(self, src, tgt, hyper_dev) -> torch.Tensor:
+        losses, _ = self.losses_and_grads(src, tgt, update=True, hyper_dev=hyper_dev)
         if self.sync_loss:
             work = all_reduce_mean_scalar(losses, self.pg)
             if work is not None:
                 work.wait()
                 ops.axpy_(losses, losses, 1.0 / dist.get_world_size(self.pg) - 1.0)     # x += (1/w - 1) x
         return losses
+
+    def _step_graphed(self, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        key = (tuple(src.shape), tuple(tgt.shape), src.device, self.overlap_wgrad)
+        if self._captured is None or self._captured[0] != key:
+            if self._warm_key != key:       # first step of this shape: eager (module load, LDS attributes, workspaces)
+                self._warm_key, self._captured = key, None
+                return self._step_body(src, tgt, None)
+            s_src = torch.empty_like(src, dtype=torch.float32).contiguous()
+            s_tgt = torch.empty_like(tgt, dtype=torch.float32).contiguous()
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                losses = self._step_body(s_src, s_tgt, self._hyper.dev)
+            self._captured = (key, graph, s_src, s_tgt, losses)
+        _, graph, s_src, s_tgt, losses = self._captured
+        s_src.copy_(src); s_tgt.copy_(tgt)
+        self.pD.step_count += 1
+        self.pG.step_count += 1
+        if self.pD.step_count != self.pG.step_count:
+            raise RuntimeError("graph=True: the two optimisers must have taken the same number of steps")
+        self._hyper.push(ops.adam_hyper(self.pG.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                        self.pG.bucketer.grad_scale))
+        graph.replay()
+        return losses.clone()
 
     @torch.no_grad()
     def generate(self, src: torch.Tensor) -> torch.Tensor:

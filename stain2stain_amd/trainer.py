@@ -92,8 +92,13 @@ class CFMTrainer:
     def __init__(self, net: FlowUNet, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, sigma: float = 0.0,
                  bucket_mb: float = 4.0, process_group=None, sync_loss: bool = True, max_bucket_mb: float = 16.0,
-                 sharded_optimizer: bool = False, sync_batchnorm: bool = False):
-        """``sharded_optimizer``: exchange gradients by reduce-scatter, run the fused Adam on this rank's 1/world of every
+                 sharded_optimizer: bool = False, sync_batchnorm: bool = False, graph: bool = False):
+        """``graph``: ``step()`` replays ONE captured hipGraph per optimisation step (sample -> forward -> loss -> backward
+        -> [gradient exchange] -> Adam -> repack: ~210 kernel launches, the side-stream fork / joins included) instead of
+        issuing them from Python; the first step of a batch shape runs eagerly (it is also the warm-up), the second
+        captures.  Same kernels in the same order: bit-equal to the eager step.  The host only refreshes the eight Adam
+        scalars (step count -> bias corrections, scheduler -> lr) in device memory before each replay.
+        ``sharded_optimizer``: exchange gradients by reduce-scatter, run the fused Adam on this rank's 1/world of every
         bucket and all-gather the updated parameters (ddp.GradBucketer, mode "reduce_scatter") instead of all-reduce +
         a full Adam pass on every rank.  Same results, same wire volume, 1/world of the optimiser's HBM traffic.
         ``sync_batchnorm``: BatchNorm statistics over the global batch (Lightning's ``sync_batchnorm: True``,
@@ -156,6 +161,13 @@ class CFMTrainer:
         self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._pack_total = start
         self._repack()
+        self.graph = graph
+        self._captured = None                  # _CapturedStep of the current batch shape
+        self._warm_key = None
+        self._hyper = ops.AdamHyperRing(dev) if graph else None
+        if graph and self.bucketer.enabled and dist.get_backend(process_group) != "nccl":
+            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
+                               "collectives can be captured")
 
     # hyper-parameters live in the optimiser handle's param group (schedulers edit them there)
     @property
@@ -216,15 +228,23 @@ class CFMTrainer:
         self._group += 1
 
     def optimizer_step(self) -> None:
+        self.step_count += 1
+        self._enqueue_optimizer(None)
+        engine.mutation_epoch[0] += 1
+
+    def _enqueue_optimizer(self, hyper_dev: Optional[torch.Tensor]) -> None:
+        """Join the exchange, Adam, [parameter all-gather], repack.  ``hyper_dev``: the Adam scalars in device memory
+        (captured step) instead of kernel arguments."""
         engine.join_side(self._side)        # the weight gradients
         self.bucketer.wait_all()
-        self.step_count += 1
         for lo, hi in self.bucketer.shards():          # everything, or this rank's slices in sharded mode
-            ops.adam_step_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
-                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                           self.bucketer.grad_scale)
+            if hyper_dev is None:
+                ops.adam_step_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                               self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                               self.bucketer.grad_scale)
+            else:
+                ops.adam_step_dev_(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], hyper_dev)
         self.bucketer.all_gather(self.flat_p)
-        engine.mutation_epoch[0] += 1
         self._repack()              # master weights changed behind torch's version counter
 
     # ------------------------------------------------------------------------------------------
@@ -281,10 +301,57 @@ class CFMTrainer:
 
     def step(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One training step on this rank's shard of the global batch; returns the (rank-mean) loss."""
+        if self.graph and ops._PROFILE is None:
+            return self._step_graphed(x0, x1, t)
+        self.step_count += 1
+        loss = self._step_body(x0, x1, t, None)
+        engine.mutation_epoch[0] += 1
+        return loss
+
+    def _step_body(self, x0, x1, t, hyper_dev) -> torch.Tensor:
         loss, _ = self.forward_backward(x0, x1, t, want_v=False)
         work = all_reduce_mean_scalar(loss, self.pg) if self.sync_loss else None
-        self.optimizer_step()
+        self._enqueue_optimizer(hyper_dev)
         if work is not None:
             work.wait()
             loss = loss / dist.get_world_size(self.pg)
         return loss
+
+    def _step_graphed(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor]) -> torch.Tensor:
+        B = x0.shape[0]
+        if t is None:
+            t = torch.rand(B, device=x0.device, dtype=torch.float32)
+        if self.sigma != 0.0:
+            raise NotImplementedError("graph=True with sigma != 0: the path noise is drawn inside forward_backward")
+        key = (tuple(x0.shape), x0.device, self.overlap_wgrad)
+        self.step_count += 1
+        if self._captured is None or self._captured.key != key:
+            if self._warm_key != key:       # first step of this shape: eager (module load, LDS attributes, workspaces)
+                self._warm_key, self._captured = key, None
+                loss = self._step_body(x0, x1, t, None)
+                engine.mutation_epoch[0] += 1
+                return loss
+            cap = _CapturedStep(key, x0, x1, t)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(cap.graph):
+                cap.loss = self._step_body(cap.x0, cap.x1, cap.t, self._hyper.dev)
+            self._captured = cap
+        cap = self._captured
+        cap.x0.copy_(x0); cap.x1.copy_(x1); cap.t.copy_(t)
+        self._hyper.push(ops.adam_hyper(self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                        self.bucketer.grad_scale))
+        cap.graph.replay()
+        engine.mutation_epoch[0] += 1
+        return cap.loss.clone()
+
+
+class _CapturedStep:
+    """Static input buffers + the hipGraph of one optimisation step for one batch shape."""
+
+    def __init__(self, key, x0, x1, t):
+        self.key = key
+        self.x0 = torch.empty_like(x0, dtype=torch.float32).contiguous()
+        self.x1 = torch.empty_like(x1, dtype=torch.float32).contiguous()
+        self.t = torch.empty_like(t, dtype=torch.float32).contiguous()
+        self.graph = torch.cuda.CUDAGraph()
+        self.loss = None

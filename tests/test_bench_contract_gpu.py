@@ -37,11 +37,33 @@ def test_training_line_has_the_contract_keys():
     assert abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the training steps are replayed hipGraphs by default, with the eager figure of the same trainer beside it
+    assert "hipGraph" in d["config"]["launch"] and d["config"]["eager_ms_per_step"] > 0
+    assert "hipGraph" in p["config"]["launch"] and p["config"]["eager_ms_per_step"] > 0
+    # the driver's default line times what DESIGN quotes -- configs[3] (batch 32 x 50 Euler steps, eager
+    # and graphed, and the reference's batch 1) and the fp32 parity mode of the headline step
+    sm = d["sample"]
+    for b in ("batch32", "batch1"):
+        for how in ("eager", "graph"):
+            r = sm[b][how]
+            assert r["finite"] is True and r["tiles_per_s"] > 1 and abs(r["ms_per_euler_step"] * 50 - r["ms_per_solve"]) < 0.05
+    assert sm["value"] == sm["batch32"]["graph"]["tiles_per_s"] and sm["batch1"]["graph"]["ms_per_euler_step"] < 2.0
+    fp = d["fp32_parity"]
+    assert fp["unit"] == "tiles/s" and 50 < fp["value"] < d["value"] and fp["dtype"].startswith("fp32")
 
 
 def test_sampling_line():
     d = _run("--mode", "sample", "--euler-steps", "3", "--no-cpu-baseline")
     assert d["unit"] == "tiles/s" and d["config"]["finite"] is True and d["roofline"]["achieved"] > 100
+
+
+def test_sampling_line_full_50_euler_steps_batch_32():
+    """BASELINE.json configs[3] as worded: batch 32, 50 Euler steps, once eagerly and once as replayed graphs."""
+    d = _run("--mode", "sample", "--euler-steps", "50", "--no-cpu-baseline", steps=1)
+    assert d["config"]["finite"] is True and d["config"]["global_batch"] == 32 and d["value"] > 50
+    assert abs(d["config"]["ms_per_euler_step"] * 50 - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    g = _run("--mode", "sample", "--euler-steps", "50", "--no-cpu-baseline", "--graph", steps=1)
+    assert g["config"]["finite"] is True and g["value"] > 50
 
 
 def test_pix2pix_line():

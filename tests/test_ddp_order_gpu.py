@@ -142,7 +142,17 @@ def _rccl_main(rank, port, out_dir):
         ok = ok and torch.equal(g, ref[s][0]) and l == ref[s][1]
     torch.cuda.synchronize()
     ok = ok and torch.equal(tr.flat_p.cpu(), ref_p)
-    torch.save({"ok": bool(ok), "buckets": len(tr.bucketer.buckets)}, os.path.join(out_dir, "rccl.pt"))
+    # the same two steps as ONE replayed hipGraph each, the RCCL collectives captured inside it (graph=True)
+    graph_err = ""
+    try:
+        gtr = CFMTrainer(_unet(100), lr=1e-4, bucket_mb=0.5 / 1024, max_bucket_mb=4.0 / 1024, graph=True)
+        gl = [float(gtr.step(x0.cuda(), x1.cuda(), t[s].cuda())) for s in range(2)]
+        torch.cuda.synchronize()
+        graph_ok = gtr._captured is not None and torch.equal(gtr.flat_p.cpu(), ref_p) and gl == [ref[0][1], ref[1][1]]
+    except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test with the message
+        graph_ok, graph_err = False, repr(e)[:500]
+    torch.save({"ok": bool(ok), "buckets": len(tr.bucketer.buckets), "graph_ok": bool(graph_ok), "graph_err": graph_err},
+               os.path.join(out_dir, "rccl.pt"))
     dist.destroy_process_group()
 
 
@@ -151,3 +161,4 @@ def test_rccl_small_buckets_bit_equal_to_the_collective_free_trainer(tmp_path):
     mp.spawn(_rccl_main, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=True)
     assert r["ok"] and r["buckets"] >= 8
+    assert r["graph_ok"], "graph=True with captured RCCL collectives: " + r["graph_err"]

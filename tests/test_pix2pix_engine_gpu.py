@@ -228,8 +228,8 @@ def _oracle_eval(Go, Do, src, tgt, dtype=torch.float32):
     return fake.detach().double(), float(ld.detach()), float(lg.detach()), grads
 
 
-def _screened_batch(Go, Do, shape, first_seed):
-    """First data seed on which the oracle's own gradients agree to 2e-4 across fp32, fp64 and 3e-7-jittered fp64."""
+def _screened_batch(Go, Do, shape, first_seed, accept=2e-4):
+    """First data seed on which the oracle's own gradients agree to ``accept`` (2e-4) across fp32, fp64 and 3e-7-jittered fp64."""
     for seed in range(first_seed, first_seed + 60):
         g = torch.Generator().manual_seed(seed)
         src, tgt = torch.rand(*shape, generator=g) * 2 - 1, torch.rand(*shape, generator=g) * 2 - 1
@@ -245,7 +245,7 @@ def _screened_batch(Go, Do, shape, first_seed):
             worst = max(worst, max(float((other[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale)
                                    for k in ref))
         print(f"  data seed {seed}: oracle gradients under fp32 / fp64 / jitter move by {worst:.2e}")
-        if worst < 2e-4:
+        if worst < accept:
             return src, tgt
     raise RuntimeError("no well-conditioned draw found")
 
@@ -291,7 +291,10 @@ def test_baseline_config0_literal_form_2_level_unet_1_layer_patchgan():
     from stain2stain_amd.pix2pix import pix2pix_step
     G, D, Go, Do = _build(16, 16, 2, 1984, bf16_weights=False, n_layers=1)
     assert len(G.downs) == 2 and [k for _, k, _ in D.conv_layers()] == ["s2", "s1", "s1"]
-    src, tgt = _screened_batch(Go, Do, (4, 3, 64, 64), 1984)
+    # a generator this shallow has no InstanceNorm at all and 16k ReLU / LeakyReLU decisions on raw conv outputs: the
+    # oracle's OWN gradients move by 4e-4 ... 5e-3 between fp32, fp64 and a 3e-7 input jitter on every draw tried, so the
+    # draw is screened at 1e-3 and the gradients are held to 3x that; output and losses stay at 1e-3
+    src, tgt = _screened_batch(Go, Do, (4, 3, 64, 64), 1984, accept=1e-3)
     fake_o, ld_o, lg_o, gref = _oracle_eval(Go, Do, src, tgt, torch.float64)
     tr = Pix2PixTrainer(G, D, precision="fp32", lr=2e-4)
     losses, fake = tr.losses_and_grads(src.to(DEV), tgt.to(DEV), update=False, want_fake=True)
@@ -302,7 +305,7 @@ def test_baseline_config0_literal_form_2_level_unet_1_layer_patchgan():
         scale = max(float(v.abs().max()) for k, v in gref.items() if k.startswith(net))
         for k, r in gref.items():
             if k.startswith(net):
-                assert float((got[k] - r).abs().max()) <= TOL * max(float(r.abs().max()), 1e-3 * scale), k
+                assert float((got[k] - r).abs().max()) <= 3 * TOL * max(float(r.abs().max()), 1e-3 * scale), k
     og = torch.optim.Adam(Go.parameters(), lr=2e-4, betas=(0.5, 0.999))
     od = torch.optim.Adam(Do.parameters(), lr=2e-4, betas=(0.5, 0.999))
     for _ in range(2):
