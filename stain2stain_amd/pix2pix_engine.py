@@ -265,10 +265,7 @@ class Pix2PixTrainer:
         self.last: Dict[str, torch.Tensor] = {}
         self.graph = graph
         self._captured, self._warm_key = None, None
-        self._hyper = ops.AdamHyperRing(dev) if graph else None
-        if graph and self.pG.bucketer.enabled and dist.get_backend(process_group) != "nccl":
-            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
-                               "collectives can be captured")
+        self._hyper = None                     # ops.AdamHyperRing, created with the first captured step
 
     def optimizer_state_dict(self) -> Dict:
         """Both Adam states (by parameter name) + hyper-parameters; a collective with ``sharded_optimizer`` (FlatParams.state_dict)."""
@@ -500,6 +497,11 @@ class Pix2PixTrainer:
 
     def _step_graphed(self, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
         key = (tuple(src.shape), tuple(tgt.shape), src.device, self.overlap_wgrad)
+        if self.pG.bucketer.enabled and dist.get_backend(self.pg) != "nccl":
+            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
+                               "collectives can be captured")
+        if self._hyper is None:
+            self._hyper = ops.AdamHyperRing(src.device)
         if self._captured is None or self._captured[0] != key:
             if self._warm_key != key:       # first step of this shape: eager (module load, LDS attributes, workspaces)
                 self._warm_key, self._captured = key, None

@@ -164,10 +164,7 @@ class CFMTrainer:
         self.graph = graph
         self._captured = None                  # _CapturedStep of the current batch shape
         self._warm_key = None
-        self._hyper = ops.AdamHyperRing(dev) if graph else None
-        if graph and self.bucketer.enabled and dist.get_backend(process_group) != "nccl":
-            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
-                               "collectives can be captured")
+        self._hyper = None                     # ops.AdamHyperRing, created with the first captured step
 
     # hyper-parameters live in the optimiser handle's param group (schedulers edit them there)
     @property
@@ -323,6 +320,11 @@ class CFMTrainer:
             t = torch.rand(B, device=x0.device, dtype=torch.float32)
         if self.sigma != 0.0:
             raise NotImplementedError("graph=True with sigma != 0: the path noise is drawn inside forward_backward")
+        if self.bucketer.enabled and dist.get_backend(self.pg) != "nccl":
+            raise RuntimeError("stain2stain_amd: graph=True captures the gradient exchange; only RCCL ('nccl') "
+                               "collectives can be captured")
+        if self._hyper is None:
+            self._hyper = ops.AdamHyperRing(x0.device)
         key = (tuple(x0.shape), x0.device, self.overlap_wgrad)
         self.step_count += 1
         if self._captured is None or self._captured.key != key:
