@@ -34,10 +34,11 @@ def hipcc() -> str:
     return "hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def needs_build(lib_path: str = None) -> bool:
+    lib_path = lib_path or LIB_PATH
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib_path)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
@@ -46,7 +47,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 4, ablate: boo
     """Compile every HIP source for gfx950 and link the shared library in-tree.  ``ablate``: the -DS2S_ABLATE variant
     (libstain2stain_hip_ablate.so, for scripts/ -- set S2S_LIB=ablate before importing the package to load it)."""
     if ablate:
-        return _build_to(ABLATE_LIB_PATH, os.path.join(HERE, "build_ablate"), ["-DS2S_ABLATE"], True, verbose, jobs)
+        if not force and not needs_build(ABLATE_LIB_PATH):
+            return ABLATE_LIB_PATH
+        return _build_to(ABLATE_LIB_PATH, os.path.join(HERE, "build_ablate"), ["-DS2S_ABLATE"], force, verbose, jobs)
     if not force and not needs_build():
         return LIB_PATH
     return _build_to(LIB_PATH, os.path.join(HERE, "build"), [], force, verbose, jobs)
@@ -120,8 +123,7 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if os.environ.get("S2S_LIB") == "ablate":          # scripts/ only (timing ablations; results may be wrong)
-            if not os.path.exists(ABLATE_LIB_PATH):
-                build(ablate=True)
+            build(ablate=True, jobs=6)         # (no-op when the library is newer than every source)
             _lib = ctypes.CDLL(ABLATE_LIB_PATH)
         elif not os.path.exists(LIB_PATH):
             import fcntl                   # one rank of a multi-process launch builds, the others wait for it

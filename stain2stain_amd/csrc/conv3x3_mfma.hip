@@ -936,9 +936,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     const int it0 = (c - c_lo) * 9;
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
-      if (tap == 0) dma_halo(c + 1);
-      dma_w((it0 + tap + NS - 1) % NS);
-      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      if (tap == 0) { if (!S2S_ABL(a.dbg & 4)) dma_halo(c + 1); else { static_for<HG>([&](auto) { dma16(g_zero_page, ldsA + ((c + 1) & 1) * A_BYTES + wave * 1024); }); } }
+      if (!S2S_ABL(a.dbg & 1)) dma_w((it0 + tap + NS - 1) % NS);
+      else { static_for<BG>([&](auto) { dma16(g_zero_page, ldsB + wave * 1024); }); }
+      if (!S2S_ABL(a.dbg & 2)) compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
       __builtin_amdgcn_sched_barrier(0);
       wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
       __builtin_amdgcn_s_barrier();

@@ -151,7 +151,7 @@ class GraphedVelocity:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with ops.capture_graph(self.graph):
             if dt is not None:
                 ops.euler_tick_(self.t, self._table, self._counter)
             self.v = net(self.t, self.x).contiguous()

@@ -705,6 +705,33 @@ def adam_hyper(step: int, lr: float, beta1: float, beta2: float, eps: float, wei
     return [float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, math.sqrt(bc2), float(grad_scale)]
 
 
+class capture_graph:
+    """``torch.cuda.graph(g)`` with Python's cyclic collector out of the way.  A collection that runs DURING a capture can
+    destroy an earlier, unreachable ``torch.cuda.CUDAGraph`` (e.g. the sampler's GraphedVelocity, which forms a cycle with
+    its network): hipGraphExecDestroy / the release of its private memory pool inside another stream capture aborts the
+    process (seen on ROCm 7 / torch 2.10, whose ``torch.cuda.graph`` no longer collects on entry).  So: collect first,
+    keep the collector off while capturing, restore it afterwards."""
+
+    def __init__(self, graph: "torch.cuda.CUDAGraph"):
+        self._ctx = torch.cuda.graph(graph)
+
+    def __enter__(self):
+        import gc
+        self._gc = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        torch.cuda.synchronize()
+        return self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._gc:
+                gc.enable()
+
+
 class AdamHyperRing:
     """The eight Adam scalars of a captured training step: ``dev`` is what the replayed kernel reads; ``push`` refreshes
     it from the host in stream order without a synchronisation (pinned staging slots, each re-used only after the copy

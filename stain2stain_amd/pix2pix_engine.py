@@ -510,7 +510,7 @@ class Pix2PixTrainer:
             s_tgt = torch.empty_like(tgt, dtype=torch.float32).contiguous()
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with ops.capture_graph(graph):
                 losses = self._step_body(s_src, s_tgt, self._hyper.dev)
             self._captured = (key, graph, s_src, s_tgt, losses)
         _, graph, s_src, s_tgt, losses = self._captured

@@ -335,7 +335,7 @@ class CFMTrainer:
                 return loss
             cap = _CapturedStep(key, x0, x1, t)
             torch.cuda.synchronize()
-            with torch.cuda.graph(cap.graph):
+            with ops.capture_graph(cap.graph):
                 cap.loss = self._step_body(cap.x0, cap.x1, cap.t, self._hyper.dev)
             self._captured = cap
         cap = self._captured
