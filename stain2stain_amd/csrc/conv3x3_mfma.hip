@@ -76,9 +76,16 @@ struct Conv3x3Args {
   // every XCD has its own L2, so the grid is cut into xsp x xsn = 8 blocks (pixel-tile ranges x output-channel-tile
   // ranges), one per XCD, walked output-channel tile fastest; xsp = 0 = the plain order.
   int xsp, xsn;
+  int direct_ep;   // 1: launches without statistics store straight from the accumulators (conv_epilogue16_direct); S2S_CONV_EPI=lds: 0
   int dbg;   // S2S_CONV_DBG: 64 = clock probe, 128 = old LDS slot key; -DS2S_ABLATE builds only: bit0 = no weight DMA in the
              // 32x32x16 loop, bit1 = no MFMA, bit2 = no halo DMA, 8 = no global stores, 16 = no epilogue
 };
+
+// S2S_CONV_EPI=lds: the LDS-staged epilogue also for launches without statistics (A/B switch; same results)
+static int direct_ep_default() {
+  static const int v = [] { const char* e = getenv("S2S_CONV_EPI"); return !(e && e[0] == 'l'); }();
+  return v;
+}
 
 namespace {
 
@@ -790,6 +797,81 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
   }
 }
 
+// Epilogue of the 16x16x32 kernels for launches WITHOUT statistics (every data gradient, the eval-mode forward, the 4x4
+// layers of row a13): straight from the accumulators to global memory, no LDS staging, no barrier.  A lane holds four
+// consecutive channels of one pixel per 16 x 16 block; v_permlane16_swap exchanges the odd 16-lane rows of block ni with
+// the even rows of block ni + 1, after which every lane owns EIGHT consecutive channels of its pixel -- one 16-byte
+// store, and the four lanes of a pixel cover 64 contiguous bytes (two stores complete a 128-byte line of a 64-channel
+// tile).  (The LDS-staged form spends ~3 us per workgroup on its write / barrier / read-back; a 64 -> 64 layer at 256^2
+// has 18 taps = 6.8 us of main loop per tile, and the data gradients take no statistics: measured 40 of 132 us there.)
+template <int TH, int TW, int BN, int WM, int WN, bool AFFINE>
+__device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
+                                                       const float (&bias)[(BN / WN) / 16][4], int img, int y0, int x0p,
+                                                       int n0, int tid, const OutMap om) {
+  using T = bf16_t;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  static_assert(NI % 2 == 0, "channel blocks are exchanged in pairs");
+  T* __restrict__ yout = static_cast<T*>(a.y);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int cl = lane & 15, q = lane >> 4;
+  float esc[NI][4], esh[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * WTN + ni * 16 + 4 * q + j;
+      const bool nok = n < a.Cout;
+      esc[ni][j] = (AFFINE && nok) ? a.ep_scale[n] : 1.f;
+      esh[ni][j] = (AFFINE && nok) ? a.ep_shift[n] : 0.f;
+    }
+  // after the exchange this lane holds channels [blk * 16 + (q >> 1) * 8, + 8) with blk = ni + (q & 1)
+  const int nlane = n0 + wn * WTN + (q & 1) * 16 + (q >> 1) * 8;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 16 + cl;
+    const int py = m / TW, px = m - py * TW;
+    const int gy = y0 + py, gx = x0p + px;
+    const bool pok = gy < a.H && gx < a.W;
+    const long opix = ((long)img * om.OH + gy * om.os + om.oy) * om.OW + gx * om.os + om.ox;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni += 2) {
+      unsigned w[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bf16x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = acc[mi][ni + b][j] + bias[ni + b][j];
+          if (AFFINE) {
+            t = t * esc[ni + b][j] + esh[ni + b][j];
+            if (a.relu) t = fmaxf(t, 0.f);
+          } else if (a.act) {
+            t = t > 0.f ? t : a.act_slope * t;
+          }
+          pk[j] = (bf16_t)t;
+        }
+        const uint2 u = __builtin_bit_cast(uint2, pk);
+        w[b][0] = u.x; w[b][1] = u.y;
+      }
+      const auto r0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+      const uint4 out = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      const int n = nlane + ni * 16;
+      if (pok && n < a.Cout) {
+        if (!S2S_ABL(a.dbg & 8)) *reinterpret_cast<uint4*>(yout + opix * a.ldy + n) = out;
+        if (a.y2) {
+          const bf16x8 val = __builtin_bit_cast(bf16x8, out);
+          bf16x8 r8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) r8[k] = (float)val[k] > 0.f ? val[k] : (bf16_t)0.f;
+          *reinterpret_cast<bf16x8*>(static_cast<T*>(a.y2) + opix * a.ldy2 + n) = r8;
+        }
+      }
+    }
+  }
+}
+
 // S2S_CONV_DBG=64: thread 0 of each workgroup records the shader-clock counter and the 100 MHz wall clock at entry
 // and exit (read back with s2s_debug_conv_clock): the clock the kernel actually ran at under its own load.
 __device__ long g_clk[8192 * 4];
@@ -805,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
   constexpr int B_BYTES = BN * 64;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int RB = TW / 16;                        // 16-pixel blocks per tile row
-  static_assert(WM * WN == 4 && BN % 64 == 0 && (NS == 3 || NS == 4) && TW % 16 == 0 && WTM % TW == 0, "configuration");
+  static_assert(WM * WN == 4 && BN % 64 == 0 && NS >= 3 && NS <= 8 && TW % 16 == 0 && WTM % TW == 0, "configuration");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsA = smem;
@@ -938,11 +1020,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       constexpr int tap = decltype(tapc)::value;
       if (tap == 0) { if (!S2S_ABL(a.dbg & 4)) dma_halo(c + 1); else { static_for<HG>([&](auto) { dma16(g_zero_page, ldsA + ((c + 1) & 1) * A_BYTES + wave * 1024); }); } }
       if (!S2S_ABL(a.dbg & 1)) dma_w((it0 + tap + NS - 1) % NS);
-      else { static_for<BG>([&](auto) { dma16(g_zero_page, ldsB + wave * 1024); }); }
+      else if (!S2S_ABL(a.dbg & 512)) { static_for<BG>([&](auto) { dma16(g_zero_page, ldsB + wave * 1024); }); }
       if (!S2S_ABL(a.dbg & 2)) compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
       __builtin_amdgcn_sched_barrier(0);
-      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
-      __builtin_amdgcn_s_barrier();
+      if (!S2S_ABL(a.dbg & 256)) wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
+      if (!S2S_ABL(a.dbg & 32)) __builtin_amdgcn_s_barrier();
     });
   }
   // the epilogue's per-channel bias: fetched here so that the load latency hides behind the last nine taps
@@ -962,7 +1044,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       if (tap + NS - 1 < 9) dma_w((it0 + tap + NS - 1) % NS);
       compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
       __builtin_amdgcn_sched_barrier(0);
-      if (tap + NS - 1 < 9) wait_vm<(NS - 2) * BG>(); else wait_vm<0>();
+      // slab tap + 1 must have landed; the slabs issued after it (up to the chunk's last one) may stay in flight
+      constexpr int last_issued = (tap + NS - 1 < 9) ? tap + NS - 1 : 8;
+      constexpr int younger = last_issued - (tap + 1) > 0 ? last_issued - (tap + 1) : 0;
+      wait_vm<younger * BG>();
       __builtin_amdgcn_s_barrier();
     });
   }
@@ -986,7 +1071,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     return;
   }
   const OutMap om{1, 0, 0, a.H, a.W};
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
+  if (!a.stat_part && a.direct_ep) {      // no statistics to take: registers -> global memory (conv_epilogue16_direct)
+    if (a.ep_scale) conv_epilogue16_direct<TH, TW, BN, WM, WN, true>(a, acc, biasr, img, y0, x0p, n0, tid, om);
+    else conv_epilogue16_direct<TH, TW, BN, WM, WN, false>(a, acc, biasr, img, y0, x0p, n0, tid, om);
+  } else if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
   if ((a.dbg & 64) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4 + 0] = c0_; g_clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter(); g_clk[blockIdx.x * 4 + 2] = w0_; g_clk[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
@@ -1225,7 +1313,10 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   }
   // (per-tile statistics rows are only defined for the single-phase forms)
   const long stat_row = MODE == 2 ? -1 : (long)blockIdx.x;
-  if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
+  if (!a.stat_part && a.direct_ep) {
+    if (a.ep_scale) conv_epilogue16_direct<TH, TW, BN, WM, WN, true>(a, acc, biasr, img, y0, x0p, n0, tid, om);
+    else conv_epilogue16_direct<TH, TW, BN, WM, WN, false>(a, acc, biasr, img, y0, x0p, n0, tid, om);
+  } else if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
 }
 
@@ -1720,6 +1811,18 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
     }
   }
 #endif
+  // weight ring depth: four slots everywhere.  S2S_CONV_NS=8 gives the 64-channel tiles seven taps of DMA lead (80 KB of
+  // LDS, still two workgroups per CU): measured in round 3 on the 256^2 layers, whose taps run at ~46 % of the MFMA rate,
+  // and no faster (250 vs 242 us on 192 -> 64) -- the slab's round trip is not what those taps wait for.
+  static const int ns64 = [] { const char* e = getenv("S2S_CONV_NS"); return e ? atoi(e) : 4; }();
+  if (ns64 == 8)
+    switch (id) {
+      case 1: return launch_dma16<8, 32, 64, 4, 1, 8>(a, s);
+      case 3: return launch_dma16<4, 32, 64, 2, 2, 8>(a, s);
+      case 5: return launch_dma16<16, 16, 64, 4, 1, 8>(a, s);
+      case 7: return launch_dma16<8, 16, 64, 2, 2, 8>(a, s);
+      default: break;
+    }
   switch (id) {
     case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
     case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
@@ -1742,7 +1845,7 @@ int s2s_internal_stem_fwd(int dtype, const float* x_nchw, const float* w_oihw, c
   a.x0 = a.x1 = a.w = nullptr; a.bias = bias; a.y = y; a.stat_part = stat_part;
   a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout;
   a.ld0 = a.c0 = a.ld1 = a.c1 = 0; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = 1; a.relu = 0; a.dbg = 0;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = 1; a.relu = 0; a.dbg = 0; a.direct_ep = direct_ep_default();
   a.tilesX = a.tilesY = 0;
   if (dtype == S2S_BF16) return launch_stem<bf16_t>(a, x_nchw, w_oihw, Cin, s);
   if (dtype == S2S_F32) return launch_stem<float>(a, x_nchw, w_oihw, Cin, s);
@@ -1822,6 +1925,7 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
   // S2S_CONV_DBG: 64 = clock probe, 128 = the earlier LDS slot key (both leave the results unchanged); the
   // result-changing timing ablations (bits 1-32) exist only in -DS2S_ABLATE builds
   { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return (e ? atoi(e) : 0) & S2S_DBG_MASK; }(); a.dbg = dbg; }
+  a.direct_ep = direct_ep_default();
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   a.ksplit = (kwork && !stat_part) ? s2s_conv3x3_ksplit(dtype, B, H, W, Cout, c0 + c1) : 1;
@@ -1893,7 +1997,7 @@ extern "C" int s2s_convkxk_nhwc(int dtype, const void* x, int ldx, int cin, cons
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
   if (a.kpart && stat_part) return S2S_ERR_SHAPE;                   // split launches do not produce statistics
   a.ld0 = ldx; a.c0 = cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(cin, 32); a.relu = 0; a.dbg = 0; a.direct_ep = direct_ep_default();
   a.tilesX = a.tilesY = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wide = W > 16, big = Cout > 64;
@@ -2021,7 +2125,7 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
   a.ep_scale = a.ep_shift = nullptr; a.act = act ? 1 : 0; a.act_slope = act_slope; a.y2 = y2; a.ldy2 = ldy2;
   a.bias_mod = Cout; a.lgc = __builtin_ctz((unsigned)Cin);
   a.ld0 = ldx; a.c0 = 4 * Cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(4 * Cin, 32); a.relu = 0; a.dbg = 0;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(4 * Cin, 32); a.relu = 0; a.dbg = 0; a.direct_ep = direct_ep_default();
   a.tilesX = a.tilesY = 0;
   a.ksplit = kwork ? s2s_conv4x4s2_ksplit(B, H, W, Cout, Cin) : 1;
   a.kpart = a.ksplit > 1 ? kwork : nullptr;
@@ -2068,7 +2172,7 @@ extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, c
   a.ep_scale = a.ep_shift = nullptr; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8;
   a.bias_mod = C; a.lgc = 0;
   a.ld0 = ldx; a.c0 = Cin; a.ld1 = 8; a.c1 = 0; a.ldy = ldy;
-  a.B = B; a.H = h; a.W = w; a.Cout = C; a.nchunk = cdiv(Cin, 32); a.relu = 0; a.dbg = 0;
+  a.B = B; a.H = h; a.W = w; a.Cout = C; a.nchunk = cdiv(Cin, 32); a.relu = 0; a.dbg = 0; a.direct_ep = direct_ep_default();
   a.tilesX = a.tilesY = 0;
   a.ksplit = kwork ? s2s_convt4x4s2_ksplit(B, h, w, C, Cin) : 1;
   a.kpart = a.ksplit > 1 ? kwork : nullptr;

@@ -3,7 +3,8 @@ the convolution parity tests in child processes, so that a non-default path cann
   S2S_WGRAD_KH=1 / 2      kernel rows of the weight gradient over three workgroups / over the teams of a 12-wave workgroup
   S2S_CONV_XCD=0, S2S_WGRAD_XCD=0   plain (not XCD-aware) workgroup order
   S2S_WGRAD_DMA=0         register-staged weight gradient
-  S2S_WGRAD_MFMA=16       weight gradient on 16x16x32 MFMAs (half-swapped LDS rows)"""
+  S2S_WGRAD_MFMA=16       weight gradient on 16x16x32 MFMAs (half-swapped LDS rows)
+  S2S_CONV_EPI=lds        LDS-staged epilogue also for the launches without statistics (default: registers -> global)"""
 import os
 import subprocess
 import sys
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = [{"S2S_WGRAD_KH": "1"}, {"S2S_WGRAD_KH": "2"}, {"S2S_CONV_XCD": "0", "S2S_WGRAD_XCD": "0"},
-            {"S2S_WGRAD_DMA": "0"}, {"S2S_WGRAD_MFMA": "16"}]
+            {"S2S_WGRAD_DMA": "0"}, {"S2S_WGRAD_MFMA": "16"}, {"S2S_CONV_EPI": "lds"}]
 # (The earlier forms of the forward loop, S2S_CONV_DMA=1/3/0, and the result-changing S2S_CONV_DBG timing bits are NOT in
 #  the product library any more: they are compiled only with -DS2S_ABLATE into libstain2stain_hip_ablate.so, which
 #  scripts/ load; tests/test_native_cpu.py checks that the shipped sources read no such switch outside that guard.)
