@@ -109,6 +109,12 @@ int s2s_head_loss_fused(int dtype, const void* x, int ldx, const float* w, const
 int s2s_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long* num_batches_tracked, float momentum, float eps,
                     float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* the same when the statistics were taken of the convolution WITHOUT its bias (conv_bias: [C] or NULL): mean / invstd /
+ * scale / shift refer to the unbiased conv output the caller stores, the running mean is that of conv + bias, as
+ * nn.BatchNorm2d behind nn.Conv2d(bias=True) keeps it (shared_encoder.py:15-16) */
+int s2s_bn_finalize_b(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, long* num_batches_tracked, float momentum, float eps,
+                      float* mean, float* invstd, float* scale, float* shift, const float* conv_bias, void* stream);
 int s2s_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift, void* stream);
 /* y = relu(x*scale+shift); pool (optional) = 2x2/stride-2 max of y, floor mode */

@@ -1,0 +1,82 @@
+"""Summarise rocprofv3 --pmc SQ / GRBM passes (scripts/profile_round.sh: <out>/pmc_sq1, pmc_sq2 and, for the pix2pix
+step, p2p_pmc_sq1) into profiles/<tag>_sq_counters.json: per kernel group the per-launch sums, the wave-cycle split
+(issuing / issue-stalled / parked) and a NON-SATURATED matrix-pipe utilisation from the MFMA instruction count:
+
+    mfma_util_at_clock = SQ_INSTS_MFMA * 16 cycles / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+    mfma_flops        = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512
+
+(v_mfma_f32_16x16x32_bf16 holds a SIMD's matrix pipe for 16 cycles, MI355X_MICROARCH.md cycle constants; GRBM_GUI_ACTIVE
+is reported summed over the 8 XCDs.  SQ_VALU_MFMA_BUSY_CYCLES read a saturated, identical value for every kernel in round
+2 and is kept only for reference.)"""
+import csv, json, os, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+GROUPS = {"cfm": {"conv3x3 fwd + dgrad (conv3x3_dma16_kernel + conv3x3_pers16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel"),
+                  "conv3x3_wgrad_dma_kernel": ("conv3x3_wgrad_dma_kernel",)},
+          "p2p": {"convkxk_dma16_kernel (4x4 forward / data gradient / transposed)": ("convkxk_dma16_kernel",),
+                  "convflat_dma16_kernel (inner levels)": ("convflat_dma16_kernel",),
+                  "conv2x2_wgrad_dma_kernel": ("conv2x2_wgrad_dma_kernel",)}}
+
+
+def collect(dirs):
+    acc = defaultdict(lambda: defaultdict(list))          # kernel -> counter -> values per dispatch
+    dur = defaultdict(list)
+    for d in dirs:
+        path = None
+        for root, _, files in os.walk(os.path.join(src, d)):
+            for f in files:
+                if f.endswith("counter_collection.csv"):
+                    path = os.path.join(root, f)
+        if not path:
+            continue
+        per = defaultdict(dict)
+        for row in csv.DictReader(open(path)):
+            per[(row["Dispatch_Id"], row["Kernel_Name"])][row["Counter_Name"]] = float(row["Counter_Value"])
+            if "Start_Timestamp" in row and row.get("End_Timestamp"):
+                per[(row["Dispatch_Id"], row["Kernel_Name"])]["_dur_ns"] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        for (_, k), cs in per.items():
+            for c, v in cs.items():
+                acc[k][c].append(v)
+    return acc
+
+
+out = {"note": __doc__.split("\n\n")[0].replace("\n", " ")}
+for which, dirs in (("cfm", ["pmc_sq1", "pmc_sq2"]), ("p2p", ["p2p_pmc_sq1"])):
+    acc = collect(dirs)
+    for label, needles in GROUPS[which].items():
+        ks = [k for k in acc if any(n in k for n in needles)]
+        if not ks:
+            continue
+        tot = defaultdict(float)
+        n = 0
+        for k in ks:
+            for c, vs in acc[k].items():
+                tot[c] += sum(vs)
+            n = max(n, sum(len(acc[k].get("SQ_WAVE_CYCLES", acc[k].get("SQ_INSTS_MFMA", []))) for k in [k]) + n)
+        n = sum(len(next(iter(acc[k].values()))) for k in ks)
+        e = {"launches": n}
+        for c, v in sorted(tot.items()):
+            if not c.startswith("_"):
+                e[c + "_per_launch"] = round(v / n, 1)
+        wc = tot.get("SQ_WAVE_CYCLES", 0.0)
+        if wc:
+            e["wave_cycles_split"] = {"active_inst": round(tot["SQ_ACTIVE_INST_ANY"] / wc, 3),
+                                      "wait_inst": round(tot["SQ_WAIT_INST_ANY"] / wc, 3),
+                                      "wait_any": round(tot["SQ_WAIT_ANY"] / wc, 3)}
+        if tot.get("SQ_INSTS_MFMA") and tot.get("GRBM_GUI_ACTIVE"):
+            cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma_util_at_clock"] = round(tot["SQ_INSTS_MFMA"] * 16.0 / (cyc * 1024.0), 4)
+            if tot.get("_dur_ns"):
+                e["avg_launch_us_under_pmc"] = round(tot["_dur_ns"] / n / 1e3, 2)
+                e["clock_ghz_from_grbm"] = round(cyc / tot["_dur_ns"], 3)
+                e["mfma_tflops_from_counters"] = round(tot.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / tot["_dur_ns"] / 1e3, 1)
+                e["mfma_frac_of_2.5PF"] = round(e["mfma_tflops_from_counters"] / 2500.0, 4)
+        if tot.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"], 4)
+        out[label] = e
+json.dump(out, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
+for k, v in out.items():
+    if isinstance(v, dict):
+        print(k, {x: v[x] for x in ("launches", "mfma_util_at_clock", "mfma_tflops_from_counters", "clock_ghz_from_grbm", "wave_cycles_split") if x in v})

@@ -27,15 +27,19 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(f"{src}/pmc_fetch/f_counter_collection.csv", "FETCH_SIZE")
 write = per_kernel(f"{src}/pmc_write/w_counter_collection.csv", "WRITE_SIZE")
-groups = {"conv3x3_mfma (fwd+dgrad, conv3x3_dma16_kernel)": "conv3x3_dma16_kernel",
+def _has(needle, name):
+    return any(n in name for n in needle) if isinstance(needle, tuple) else needle in name
+
+
+groups = {"conv3x3_mfma (fwd+dgrad: conv3x3_pers16_kernel + conv3x3_dma16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel"),
           "conv3x3_wgrad (conv3x3_wgrad_dma_kernel)": "conv3x3_wgrad_dma_kernel",
           "bn_relu_apply": "bn_relu_apply_kernel", "bn_relu_bwd_reduce_flat": "bn_relu_bwd_reduce_flat_kernel",
           "bn_relu_bwd_apply_flat": "bn_relu_bwd_apply_flat_kernel", "upsample2x_fwd": "upsample2x_fwd_kernel",
           "upsample2x_bwd": "upsample2x_bwd_", "adam": "adam_kernel", "head_loss": "head_loss_lanes_kernel"}
 out = {}
 for label, needle in groups.items():
-    f = [v for k, vs in fetch.items() if needle in k for v in vs]
-    w = [v for k, vs in write.items() if needle in k for v in vs]
+    f = [v for k, vs in fetch.items() if _has(needle, k) for v in vs]
+    w = [v for k, vs in write.items() if _has(needle, k) for v in vs]
     if not f or not w:
         continue
     fk, wk = sum(f) / len(f), sum(w) / len(w)
@@ -55,8 +59,8 @@ stats = list(csv.DictReader(open(f"{src}/stats/k_kernel_stats.csv")))
 for label, needle in groups.items():
     if label not in out:
         continue
-    tot = sum(float(r["TotalDurationNs"]) for r in stats if needle in r["Name"])
-    n = sum(int(r["Calls"]) for r in stats if needle in r["Name"])
+    tot = sum(float(r["TotalDurationNs"]) for r in stats if _has(needle, r["Name"]))
+    n = sum(int(r["Calls"]) for r in stats if _has(needle, r["Name"]))
     if n:
         rates[label] = {"hbm_bytes_per_launch_corrected": out[label]["hbm_bytes_per_launch_corrected"],
                         "avg_launch_us": round(tot / n / 1e3, 2),

@@ -76,6 +76,7 @@ struct Conv3x3Args {
   // every XCD has its own L2, so the grid is cut into xsp x xsn = 8 blocks (pixel-tile ranges x output-channel-tile
   // ranges), one per XCD, walked output-channel tile fastest; xsp = 0 = the plain order.
   int xsp, xsn;
+  long stat_rows;  // rows per channel of stat_part (tiles, or tiles x wave rows with the register epilogue)
   int direct_ep;   // 1: launches without statistics store straight from the accumulators (conv_epilogue16_direct); S2S_CONV_EPI=lds: 0
   int dbg;   // S2S_CONV_DBG: 64 = clock probe, 128 = old LDS slot key; -DS2S_ABLATE builds only: bit0 = no weight DMA in the
              // 32x32x16 loop, bit1 = no MFMA, bit2 = no halo DMA, 8 = no global stores, 16 = no epilogue
@@ -790,7 +791,7 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, nl = i - which * BN;
       if (n0 + nl < a.Cout && stat_row >= 0)
-        a.stat_part[((long)which * a.Cout + n0 + nl) * gridDim.x + stat_row] =
+        a.stat_part[((long)which * a.Cout + n0 + nl) * a.stat_rows + stat_row] =
             (red[(0 * 2 + which) * BN + nl] + red[(1 * 2 + which) * BN + nl]) +
             (red[(2 * 2 + which) * BN + nl] + red[(3 * 2 + which) * BN + nl]);
     }
@@ -804,10 +805,21 @@ __device__ __forceinline__ void conv_epilogue16(const Conv3x3Args& a, f32x4 (&ac
 // store, and the four lanes of a pixel cover 64 contiguous bytes (two stores complete a 128-byte line of a 64-channel
 // tile).  (The LDS-staged form spends ~3 us per workgroup on its write / barrier / read-back; a 64 -> 64 layer at 256^2
 // has 18 taps = 6.8 us of main loop per tile, and the data gradients take no statistics: measured 40 of 132 us there.)
-template <int TH, int TW, int BN, int WM, int WN, bool AFFINE>
+// STATS: BatchNorm's per-channel (sum, sum of squares) of the values AS STORED (bf16), taken in registers: after the
+// exchange a lane's eight channels are the same for all of its pixels, so it sums over its MI pixels, the sixteen pixel
+// lanes of a row are folded with four DPP row rotations, and lane 0 of each row writes the wave row's partial sums to
+// stat_part[which][channel][stat_row] -- one row per (tile, wave row), no LDS, no barrier (s2s_bn_finalize sums the rows
+// of a channel whatever their number).
+template <int BITS>
+__device__ __forceinline__ float row_ror_add(float v) {
+  // v + (v rotated right by BITS lanes inside its 16-lane row): DPP row_ror
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + BITS, 0xf, 0xf, false));
+}
+
+template <int TH, int TW, int BN, int WM, int WN, bool AFFINE, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
                                                        const float (&bias)[(BN / WN) / 16][4], int img, int y0, int x0p,
-                                                       int n0, int tid, const OutMap om) {
+                                                       int n0, int tid, const OutMap om, long stat_row = -1) {
   using T = bf16_t;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   static_assert(NI % 2 == 0, "channel blocks are exchanged in pairs");
@@ -827,6 +839,13 @@ __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32
     }
   // after the exchange this lane holds channels [blk * 16 + (q >> 1) * 8, + 8) with blk = ni + (q & 1)
   const int nlane = n0 + wn * WTN + (q & 1) * 16 + (q >> 1) * 8;
+  float s1[STATS ? NI / 2 : 1][8], s2[STATS ? NI / 2 : 1][8];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1[pr][k] = 0.f; s2[pr][k] = 0.f; }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WTM + mi * 16 + cl;
@@ -858,6 +877,17 @@ __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32
       const auto r1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
       const uint4 out = make_uint4(r0[0], r1[0], r0[1], r1[1]);
       const int n = nlane + ni * 16;
+      if constexpr (STATS) {
+        if (pok && n < a.Cout) {
+          const bf16x8 val = __builtin_bit_cast(bf16x8, out);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float t = (float)val[k];
+            s1[ni / 2][k] += t;
+            s2[ni / 2][k] = fmaf(t, t, s2[ni / 2][k]);
+          }
+        }
+      }
       if (pok && n < a.Cout) {
         if (!S2S_ABL(a.dbg & 8)) *reinterpret_cast<uint4*>(yout + opix * a.ldy + n) = out;
         if (a.y2) {
@@ -868,6 +898,29 @@ __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32
           *reinterpret_cast<bf16x8*>(static_cast<T*>(a.y2) + opix * a.ldy2 + n) = r8;
         }
       }
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float u = s1[pr][k], w2 = s2[pr][k];
+        u = row_ror_add<8>(u); u = row_ror_add<4>(u); u = row_ror_add<2>(u); u = row_ror_add<1>(u);
+        w2 = row_ror_add<8>(w2); w2 = row_ror_add<4>(w2); w2 = row_ror_add<2>(w2); w2 = row_ror_add<1>(w2);
+        s1[pr][k] = u; s2[pr][k] = w2;
+      }
+    if (cl == 0 && stat_row >= 0) {
+#pragma unroll
+      for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int n = nlane + pr * 32 + k;
+          if (n < a.Cout) {
+            a.stat_part[((long)n) * a.stat_rows + stat_row] = s1[pr][k];
+            a.stat_part[((long)a.Cout + n) * a.stat_rows + stat_row] = s2[pr][k];
+          }
+        }
     }
   }
 }
@@ -1071,12 +1124,285 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
     return;
   }
   const OutMap om{1, 0, 0, a.H, a.W};
-  if (!a.stat_part && a.direct_ep) {      // no statistics to take: registers -> global memory (conv_epilogue16_direct)
-    if (a.ep_scale) conv_epilogue16_direct<TH, TW, BN, WM, WN, true>(a, acc, biasr, img, y0, x0p, n0, tid, om);
+  if (a.direct_ep) {      // registers -> global memory (conv_epilogue16_direct), statistics in registers too
+    if (a.stat_part) conv_epilogue16_direct<TH, TW, BN, WM, WN, false, true>(a, acc, biasr, img, y0, x0p, n0, tid, om, (long)tile_id * WM + wm);
+    else if (a.ep_scale) conv_epilogue16_direct<TH, TW, BN, WM, WN, true>(a, acc, biasr, img, y0, x0p, n0, tid, om);
     else conv_epilogue16_direct<TH, TW, BN, WM, WN, false>(a, acc, biasr, img, y0, x0p, n0, tid, om);
   } else if (a.ep_scale) conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, true>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, tile_id, om);
   if ((a.dbg & 64) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4 + 0] = c0_; g_clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter(); g_clk[blockIdx.x * 4 + 2] = w0_; g_clk[blockIdx.x * 4 + 3] = wall_clock64(); }
+}
+
+// =========================================================================================================
+// PERSISTENT form of conv3x3_dma16_kernel (round 3).  One workgroup per resident slot (2 per CU) walks a sequence of
+// output tiles; the DMA streams never drain between tiles:
+//   * the halo of the NEXT tile's first chunk is issued at tap 0 of the current tile's last chunk (into the halo buffer
+//     the running chunk parity frees), and the weight ring simply continues into the next tile's first slabs, so a tile
+//     starts on landed operands -- the per-tile prologue (index arithmetic, a DMA round trip behind `vmcnt(0)`, ~2.4 us
+//     of every 12 us workgroup on the 64-channel layers at 256^2) is paid once per workgroup instead of once per tile;
+//   * the epilogue is conv_epilogue16_direct: registers -> global memory, statistics in registers, no LDS, no barrier,
+//     so it cannot collide with the prefetched halo / slabs, and its stores are simply counted into the next two taps'
+//     `vmcnt` (they are younger than the slabs those taps wait for);
+//   * no bias, no folded affine, no split-K: this kernel serves the training step (forward with BatchNorm statistics --
+//     a conv bias in front of a train-mode BatchNorm cancels in the normalised output and is accounted for in the
+//     running mean by s2s_bn_finalize -- and every data gradient); everything else stays on conv3x3_dma16_kernel.
+// Tiles are dealt as before: linear id L -> (pixel tile, channel tile) through the XCD-aware cut (a.xsp x a.xsn), and
+// workgroup w takes L = w, w + G, w + 2G, ... (G a multiple of 8: a workgroup stays inside its XCD's block).
+// Every wave issues the same number of DMAs per tap whatever the tile (zero page for padding, ragged edges and "no next
+// tile"), so all `s_waitcnt vmcnt(N)` are compile-time counts.
+// =========================================================================================================
+template <int TH, int TW, int BN, int WM, int WN, int NS, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, int ntiles, int GX, int GY) {
+  using T = bf16_t;
+  constexpr int HP = TW + 4, HH_ = TH + 2, ROWS = HH_ * HP;
+  constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + 3) / 4;
+  constexpr int A_BYTES = HG * 4 * 1024;
+  constexpr int BG = BN / 64;
+  constexpr int B_BYTES = BN * 64;
+  constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int RB = TW / 16;
+  // VMEM stores a wave issues in one epilogue of a FULL tile: the 16-byte output stores, and with statistics the
+  // 2 x 8 x NI/2 partial sums of a row's lane 0 (vmcnt counts stores too; partial tiles drain instead, see below)
+  constexpr int NST = MI * (NI / 2) + (STATS ? (NI / 2) * 16 : 0);
+  static_assert((NS - 2) * BG + HG + NST <= 63, "vmcnt is a 6-bit counter");
+  static_assert(WM * WN == 4 && BN % 64 == 0 && NS == 4 && TW % 16 == 0 && WTM % TW == 0, "configuration");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;
+  char* const ldsB = smem + 2 * A_BYTES;
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+  const char* __restrict__ wp = static_cast<const char*>(a.w);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int cl = lane & 15, kp = lane >> 4;
+  const int ctot = a.c0 + a.c1;
+  const int drow = lane >> 2, dslot = lane & 3;
+
+  // ---- tile-invariant lane geometry ----
+  // halo row / column / piece of this lane's DMA row j, packed: hy << 16 | hx << 8 | channel offset of the piece; rows of
+  // the padding columns and past the image carry hy = 0x4000 (never inside an image)
+  int ageo[HG];
+#pragma unroll
+  for (int j = 0; j < HG; ++j) {
+    const int row = (wave + 4 * j) * 16 + drow;
+    const int hy = row / HP, hx = row - hy * HP;
+    ageo[j] = (((row < ROWS && hx < TW + 2) ? hy : 0x4000) << 16) | (hx << 8) | ((dslot ^ (((hx >> 2) & 1) << 1)) * 8);
+  }
+  int aofs[RB][3];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int px = rb * 16 + cl + kw;
+      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ (((px >> 2) & 1) << 1)) << 4);
+    }
+  const int nrow = wn * WTN + cl;
+  const int bofs = nrow * 64 + ((kp ^ ((-(nrow >> 2)) & 3)) << 4);
+  int wrow_off[BG];                                    // byte offset of this lane's weight row piece inside a slab, tile n0 = 0
+#pragma unroll
+  for (int j = 0; j < BG; ++j) {
+    const int n = (wave + 4 * j) * 16 + drow;
+    wrow_off[j] = (n * 32 + ((dslot ^ ((-(n >> 2)) & 3)) * 8)) * 2;
+  }
+
+  // ---- per-tile state ----
+  struct Tile { int img, y0, x0p, n0, id; };
+  auto locate = [&](int L) {
+    int bt, by;
+    if (a.xsp) {
+      const unsigned xcd = (unsigned)L & 7u, k = (unsigned)L >> 3;
+      const unsigned xp = xcd % (unsigned)a.xsp, xn = xcd / (unsigned)a.xsp;
+      const unsigned P = (unsigned)GX / (unsigned)a.xsp, Nn = (unsigned)GY / (unsigned)a.xsn;
+      const unsigned kp_ = k / Nn, kn_ = k - kp_ * Nn;
+      bt = (int)(xp * P + kp_); by = (int)(xn * Nn + kn_);
+    } else {
+      by = L / GX; bt = L - by * GX;
+    }
+    Tile t;
+    t.id = bt;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    t.img = bt / a.tilesY;
+    t.y0 = ty * TH; t.x0p = tx * TW; t.n0 = by * BN;
+    return t;
+  };
+  // weight stream: pointer to the next slab piece this lane issues, slabs left in the tile it belongs to
+  const char* wq[BG];
+  int wqstep[BG];
+  auto wq_start = [&](int n0, bool live) {
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      const int n = (wave + 4 * j) * 16 + drow;
+      const bool ok = live && n0 + n < a.Cout;
+      wq[j] = ok ? wp + (long)n0 * 64 + wrow_off[j] : g_zero_page;
+      wqstep[j] = ok ? a.Cout * 64 : 0;
+    }
+  };
+  auto dma_w = [&](int slot) {
+    char* dst = ldsB + slot * B_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      dma16(wq[j], dst + j * 4096);
+      wq[j] += wqstep[j];
+    }
+  };
+  // Halo DMA.  The source of a chunk is uniform (the launcher sends c0 % 32 != 0 to the other kernel): one base pointer
+  // in scalar registers plus a 32-bit byte offset per lane (inputs are < 4 GB), instead of a 64-bit address per piece.
+  auto halo_pix = [&](const Tile& t, bool live, int (&apix)[HG]) {
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      const int gy = t.y0 - 1 + (ageo[j] >> 16), gx = t.x0p - 1 + ((ageo[j] >> 8) & 0xff);
+      apix[j] = (live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (t.img * a.H + gy) * a.W + gx : -1;
+    }
+  };
+  auto dma_halo = [&](const int (&apix)[HG], int c, int buf) {
+    char* dst = ldsA + buf * A_BYTES + wave * 1024;
+    const bool second = c * 32 >= a.c0;
+    const char* const base = reinterpret_cast<const char*>(second ? x1 : x0);
+    const int ld = second ? a.ld1 : a.ld0, ch0 = c * 32 - (second ? a.c0 : 0);
+    const bool inrange = c * 32 < ctot;                 // (a chunk past the channels: only when ctot % 32 != 0 rounds up)
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      const int ch = ch0 + (ageo[j] & 0xff);
+      const unsigned off = ((unsigned)apix[j] * (unsigned)ld + (unsigned)ch) * 2u;
+      const bool ok = apix[j] >= 0 && inrange && c * 32 + (ageo[j] & 0xff) < ctot;
+      const void* g = ok ? static_cast<const void*>(base + off) : static_cast<const void*>(g_zero_page);
+      dma16(g, dst + j * 4096);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+  auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int kh = tap / 3, kw = tap % 3;
+    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+  };
+
+  // ---- prologue: first tile's chunk-0 halo and first NS - 1 slabs ----
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  Tile cur = locate(L);
+  bool has_next = L + G < ntiles;
+  Tile nxt = cur;
+  if (has_next) nxt = locate(L + G);
+  int apix_cur[HG];
+  halo_pix(cur, true, apix_cur);
+  wq_start(cur.n0, true);
+  dma_halo(apix_cur, 0, 0);
+  static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });
+  wait_vm<0>();                                        // (the first tile relies on this drain: see the wait counts below)
+  __builtin_amdgcn_s_barrier();
+
+  int gc = 0;                                          // chunks this workgroup has run: halo buffer = gc & 1, slab = 9 gc + tap
+  // one chunk = nine taps.  FIRST: the tile's first chunk -- its taps 0 and 1 wait for slabs that were issued BEFORE the
+  // previous tile's epilogue, so that epilogue's NST stores are younger and are counted in.  (For the workgroup's very
+  // first tile there are no such stores; the larger count is then merely permissive, and safe, because the prologue's
+  // vmcnt(0) has already landed slabs 1 and 2.)
+  auto chunk = [&](auto firstc, int c) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    const char* Ab = ldsA + (gc & 1) * A_BYTES;
+    const int it0 = gc * 9;
+    const bool last = c + 1 == a.nchunk;
+    static_for<9>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      if (tap == 0) {                                  // the next chunk in sequence: this tile's, or the next tile's first
+        if (!last) dma_halo(apix_cur, c + 1, (gc + 1) & 1);
+        else {
+          int apix_nxt[HG];
+          halo_pix(nxt, has_next, apix_nxt);
+          dma_halo(apix_nxt, 0, (gc + 1) & 1);
+        }
+      }
+      // the ring runs NS - 1 slabs ahead: at tap 9 - (NS - 1) of a tile's last chunk it crosses into the next tile's
+      if (tap == 9 - (NS - 1) && last) wq_start(nxt.n0, has_next);
+      dma_w((it0 + tap + NS - 1) % NS);
+      compute(tapc, Ab, ldsB + ((it0 + tap) % NS) * B_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      // slab it + 1 must have landed.  Younger than it: the NS - 2 slabs issued since, the halo of tap 0 while tap <=
+      // NS - 3, and in taps 0 / 1 of a tile's first chunk the previous epilogue's stores
+      wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0) + ((FIRST && tap <= 1) ? NST : 0)>();
+      __builtin_amdgcn_s_barrier();
+    });
+    ++gc;
+  };
+  for (;;) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    chunk(std::true_type{}, 0);
+    for (int c = 1; c < a.nchunk; ++c) chunk(std::false_type{}, c);
+    {
+      const OutMap om{1, 0, 0, a.H, a.W};
+      const float nobias[NI][4] = {};
+      conv_epilogue16_direct<TH, TW, BN, WM, WN, false, STATS>(a, acc, nobias, cur.img, cur.y0, cur.x0p, cur.n0, tid, om, (long)cur.id * WM + wm);
+      // a partial tile (image edge, last channel tile) may skip store instructions whose lanes are all out of range, so
+      // its store count is not the compile-time one: drain instead (everything older has then landed, and the larger
+      // counts of the next two taps are merely permissive)
+      if (!(cur.y0 + TH <= a.H && cur.x0p + TW <= a.W && cur.n0 + BN <= a.Cout)) wait_vm<0>();
+    }
+    if (!has_next) break;
+    L += G;
+    cur = nxt;
+    halo_pix(cur, true, apix_cur);
+    has_next = L + G < ntiles;
+    if (has_next) nxt = locate(L + G);
+  }
+}
+
+template <int TH, int TW, int BN, int WM, int WN>
+int launch_pers16(Conv3x3Args& a, hipStream_t s) {
+  constexpr int NS = 4;
+  constexpr int ROWS = (TH + 2) * (TW + 4);
+  constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
+  constexpr int lds = 2 * HG * 4 * 1024 + NS * BN * 64;
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  a.tilesY = cdiv(a.H, TH);
+  a.tilesX = cdiv(a.W, TW);
+  auto kern_s = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, true>;
+  auto kern_d = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, false>;
+  static unsigned long long attr_s = 0, attr_d = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_s), lds, &attr_s)) return rc;
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_d), lds, &attr_d)) return rc;
+  const int GX = a.B * a.tilesY * a.tilesX, GY = cdiv(a.Cout, BN);
+  const long ntiles = (long)GX * GY;
+  a.stat_rows = (long)GX * WM;
+  a.xsp = 0; a.xsn = 1;
+  if (ntiles % 8 == 0) {
+    const double act = 2.0 * a.B * a.H * a.W * (a.c0 + a.c1), wb = 2.0 * 9 * (a.c0 + a.c1) * a.Cout;
+    double best = 0;
+    for (int sp = 8; sp >= 1; sp >>= 1) {
+      const int sn = 8 / sp;
+      if (GX % sp || GY % sn) continue;
+      const double cost = sn * act + sp * wb;
+      if (!a.xsp || cost < best) { best = cost; a.xsp = sp; a.xsn = sn; }
+    }
+  }
+  static const int slots = [] { const char* e = getenv("S2S_CONV_PERS_WGS"); return e ? atoi(e) : 512; }();   // 2 per CU
+  int grid = (int)(ntiles < slots ? ntiles : slots);
+  if (a.xsp && grid > 8) grid -= grid % 8;             // a stride that is a multiple of 8 keeps a workgroup inside its XCD's block
+  if (grid < 1) grid = 1;
+  if (a.stat_part) hipLaunchKernelGGL(kern_s, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
+  else hipLaunchKernelGGL(kern_d, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int NS>
@@ -1092,6 +1418,7 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   if (!a.kpart) a.ksplit = 1;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit);
+  a.stat_rows = (long)grid.x * (a.direct_ep ? WM : 1);      // (s2s_conv3x3_stat_blocks reports the same count)
   static const int xcd_aware = [] { const char* e = getenv("S2S_CONV_XCD"); return e ? atoi(e) : 1; }();
   a.xsp = 0; a.xsn = 1;
   if (xcd_aware && a.ksplit == 1 && ((long)grid.x * grid.y) % 8 == 0) {
@@ -1131,7 +1458,7 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
 //   output pixel (i, j) is pixel (2i + 1 - r, 2j + 1 - s) of the plain 2h x 2w output; its weights are rows
 //   [phase C, phase C + C) of the packed data-gradient operand (4 C rows).  a.H / a.W = h, w; a.Cout = C.  The four
 //   phases tile h x w exactly (the space-to-depth form computes (h+1) x (w+1) cells) and nothing is re-laid out.
-template <int TH, int TW, int BN, int WM, int WN, int NS, int KS, int PAD, int MODE = 0>
+template <int TH, int TW, int BN, int WM, int WN, int NS, int KS, int PAD, int MODE = 0, bool SPARSE = false>
 __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   static_assert(MODE == 0 || KS == 2, "the fused layouts exist for the 2x2-tap forms");
   using T = bf16_t;
@@ -1236,20 +1563,40 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
 
+  // SPARSE (launches with Cout <= 32 on a 64-wide tile: the image-side layers, the PatchGAN's single logit): only the
+  // 16-channel blocks of this wave's column range that hold real output channels are multiplied -- the MFMAs and fragment
+  // reads of the dead blocks were most of those launches' time.  A separate instantiation, so that the dense kernels keep
+  // their register allocation (as a run-time branch in the common kernel the 128-wide tiles spilled 880 registers).
+  const int nlive = SPARSE ? __builtin_amdgcn_readfirstlane(min(NI, max(0, (a.Cout - n0 - wn * WTN + 15) >> 4))) : NI;
   auto compute = [&](auto tapc, const char* Ab, const char* Bb) {
     constexpr int tap = decltype(tapc)::value;
     constexpr int kh = tap / KS, kw = tap % KS;
-    bf16x8 af[MI], bfr[NI];
+    if constexpr (!SPARSE) {
+      bf16x8 af[MI], bfr[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
+      for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    } else if (nlive > 0) {
+      bf16x8 af[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        if (ni < nlive) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Bb + bofs + ni * 1024);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
   };
   dma_halo(c_lo);
   static_for<NS - 1>([&](auto k) { dma_w(decltype(k)::value); });     // (c_hi - c_lo) * TAPS >= 3 slabs always exist
@@ -1320,8 +1667,11 @@ __global__ __launch_bounds__(256, 2) void convkxk_dma16_kernel(Conv3x3Args a) {
   else conv_epilogue16<TH, TW, BN, WM, WN, 2 * A_BYTES + NS * B_BYTES, false>(a, acc, biasr, smem, img, y0, x0p, n0, tid, stat_row, om);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int KS, int PAD, int MODE = 0>
+template <int TH, int TW, int BN, int WM, int WN, int KS, int PAD, int MODE = 0, bool SPARSE = false>
 int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
+  if constexpr (!SPARSE && BN == 64 && MODE == 0) {      // few real output channels on a 64-wide tile: the sparse form
+    if (a.Cout <= 32) return launch_convkxk<TH, TW, BN, WM, WN, KS, PAD, MODE, true>(a, s);
+  }
   constexpr int NS = 4;
   constexpr int ROWS = (TH + KS - 1) * (TW + 4);
   constexpr int HG = ((ROWS + 15) / 16 + 3) / 4;
@@ -1329,11 +1679,12 @@ int launch_convkxk(Conv3x3Args& a, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
-  auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD, MODE>;
+  auto kern = convkxk_dma16_kernel<TH, TW, BN, WM, WN, NS, KS, PAD, MODE, SPARSE>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   if (!a.kpart) a.ksplit = 1;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit * (MODE == 2 ? 4 : 1));
+  a.stat_rows = grid.x;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -1811,6 +2162,27 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
     }
   }
 #endif
+  // the training step's launches (forward with BatchNorm statistics, data gradients: no bias, no folded affine, no
+  // split-K) run on the persistent kernel; S2S_CONV_PERS=0: one tile per workgroup as before
+  static const int pers = [] { const char* e = getenv("S2S_CONV_PERS"); return e ? atoi(e) : 1; }();
+  // (only where a workgroup gets at least two tiles on average: with one tile each the walk buys nothing and its
+  //  bookkeeping costs 3-10 % -- measured on the 64^2 / 32^2 levels, whose grids are ~512 tiles)
+  const TileCfg& tc = kBf16Cfg[id];
+  const bool many = cfg_blocks(tc, a.B, a.H, a.W, a.Cout) >= (pers > 1 ? pers : 1024);
+  if (pers && many && a.direct_ep && !a.bias && !a.ep_scale && !a.kpart && !a.act && !a.y2 && a.nchunk >= 2 && !(a.dbg & 64) &&
+      a.c0 % 32 == 0 &&                      // a chunk reads one source; 32-bit byte offsets into each source
+      (double)a.B * a.H * a.W * a.ld0 * 2 < 4.0e9 && (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 < 4.0e9) {
+    switch (id) {      // (the 256-pixel x 128-channel tiles, ids 0 and 4, need 128 accumulator + 48 fragment registers: with the
+                       //  tile loop's state they spill, so they stay on the one-tile-per-workgroup kernel)
+      case 1: return launch_pers16<8, 32, 64, 4, 1>(a, s);
+      case 2: return launch_pers16<4, 32, 128, 2, 2>(a, s);
+      case 3: return launch_pers16<4, 32, 64, 2, 2>(a, s);
+      case 5: return launch_pers16<16, 16, 64, 4, 1>(a, s);
+      case 6: return launch_pers16<8, 16, 128, 2, 2>(a, s);
+      case 7: return launch_pers16<8, 16, 64, 2, 2>(a, s);
+      default: break;
+    }
+  }
   // weight ring depth: four slots everywhere.  S2S_CONV_NS=8 gives the 64-channel tiles seven taps of DMA lead (80 KB of
   // LDS, still two workgroups per CU): measured in round 3 on the 256^2 layers, whose taps run at ~46 % of the MFMA rate,
   // and no faster (250 vs 242 us on 192 -> 64) -- the slab's round trip is not what those taps wait for.
@@ -1868,7 +2240,15 @@ extern "C" int s2s_conv3x3_stat_blocks(int dtype, int B, int H, int W, int Cout)
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   const int id = select_cfg(dtype, B, H, W, Cout);
   const TileCfg& c = dtype == S2S_F32 ? kF32Cfg[id] : kBf16Cfg[id];
-  return B * cdiv(H, c.th) * cdiv(W, c.tw);
+  const int tiles = B * cdiv(H, c.th) * cdiv(W, c.tw);
+  if (dtype == S2S_F32 || !direct_ep_default()) return tiles;
+#ifdef S2S_ABLATE
+  { static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
+    if (use_dma != 16) return tiles; }
+#endif
+  // the register epilogue of the bf16 kernel writes one row per (tile, wave row): WM = 4 for the 64-wide 4 x 1 tiles
+  static const int wm_of[8] = {2, 4, 2, 2, 2, 4, 2, 2};
+  return tiles * wm_of[id];
 }
 
 extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
@@ -1969,8 +2349,11 @@ extern "C" int s2s_convkxk_ksplit(int dtype, int B, int H, int W, int Cout, int 
   const int th = (ks == 4 && wide) ? 4 : 8, tw = wide ? 32 : 16, bn = big ? 128 : 64;
   const long base = (long)B * cdiv(H, th) * cdiv(W, tw) * cdiv(Cout, bn);
   const int nchunk = cdiv(cin, 32);
-  if (base >= 192 || nchunk < 8) return 1;
-  long sp = (512 + base - 1) / base;
+  // a tile with a single live 16-channel block (the PatchGAN's logit layer: 512 -> 1, padded to 8) runs a quarter of a
+  // tile's MFMAs per tap, so its taps are latency-bound and more, shorter workgroups win: aim at 1024 instead of 512
+  const long target = Cout <= 16 ? 1024 : 512;
+  if (base >= (Cout <= 16 ? 512 : 192) || nchunk < 8) return 1;
+  long sp = (target + base - 1) / base;
   if (sp > nchunk / 4) sp = nchunk / 4;               // at least four chunks (16 or 64 taps) per workgroup
   if (sp > 32) sp = 32;
   return sp < 2 ? 1 : (int)sp;

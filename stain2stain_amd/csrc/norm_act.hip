@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long* num_batches, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* scale_out,
-                                   float* shift_out) {
+                                   float* shift_out, const float* __restrict__ conv_bias) {
   const int c = blockIdx.x * (256 / TPC) + threadIdx.x / TPC, li = threadIdx.x % TPC;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
   if (c >= C) return;                    // wave-uniform (TPC >= 64); never taken when TPC == 256 (grid = C)
@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     shift_out[c] = beta[c] - (float)mean * sc;
     if (running_mean) {
       const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      // conv_bias: the statistics were taken of the convolution WITHOUT its bias (the persistent conv kernel adds none:
+      // a bias in front of a train-mode BatchNorm cancels in the normalised output); the running mean is the one of the
+      // biased output, as nn.BatchNorm2d behind nn.Conv2d(bias=True) keeps it
+      const float mb = conv_bias ? (float)mean + conv_bias[c] : (float)mean;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mb;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
@@ -584,22 +588,30 @@ inline int red_blocks(int B, int H, int W, int C) {
 
 }  // namespace
 
-extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma,
-                               const float* beta, float* running_mean, float* running_var, long* num_batches,
-                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                               void* stream) {
+extern "C" int s2s_bn_finalize_b(const float* part, int nblk, int C, long count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, long* num_batches,
+                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                 const float* conv_bias, void* stream) {
   if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift) return S2S_ERR_NULL;
   if (nblk <= 0 || C <= 0 || count <= 0) return S2S_ERR_SHAPE;
   if (finalize_tpc(nblk) == 256)
     hipLaunchKernelGGL(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
                        (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
-                       invstd, scale, shift);
+                       invstd, scale, shift, conv_bias);
   else
     hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, part, nblk, C,
                        (double)count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
-                       invstd, scale, shift);
+                       invstd, scale, shift, conv_bias);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
+}
+
+extern "C" int s2s_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, long* num_batches,
+                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                               void* stream) {
+  return s2s_bn_finalize_b(part, nblk, C, count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, mean,
+                           invstd, scale, shift, nullptr, stream);
 }
 
 extern "C" int s2s_bn_partial_sums(const float* part, int nblk, int C, float* sums, void* stream) {

@@ -208,8 +208,16 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
     bn = cb.bn
     bias = cb.conv.bias.detach() if cb.conv.bias is not None else None
     if training:
+        # A conv bias in front of a train-mode BatchNorm cancels in the normalised output (and its gradient is exactly
+        # zero): the bf16 MFMA kernel is launched WITHOUT it -- its persistent form has no bias path -- and the bias only
+        # enters the running mean (ops.bn_finalize, conv_bias).  The saved conv output and the saved mean are both those
+        # of the unbiased convolution, so the backward is unchanged.  (fp32 parity mode and the stem add it as before.)
+        late_bias = None
         if stem:
             raw, stat = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=True)
+        elif dtype == torch.bfloat16 and bias is not None:
+            raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], None, cb.cout, want_stats=True)
+            late_bias = bias
         else:
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], bias, cb.cout, want_stats=True)
         count = raw.shape[0] * raw.shape[1] * raw.shape[2]
@@ -227,7 +235,7 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         st = ops.bn_finalize(stat, count, bn.weight.detach(), bn.bias.detach(),
                              bn.running_mean if track else None, bn.running_var if track else None,
                              bn.num_batches_tracked if track else None,
-                             BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps)
+                             BN_MOMENTUM if bn.momentum is None else bn.momentum, bn.eps, conv_bias=late_bias)
         act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
         return LayerCtx(x0, x1, raw, act, st, count if sx is not None else None, sx), act, pooled
     ss = cb.eval_affine()

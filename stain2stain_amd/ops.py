@@ -377,13 +377,16 @@ def head_loss_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 # ------------------------------------------------------------------------------------------------
 @_timed("bn_finalize")
 def bn_finalize(stat: torch.Tensor, count: int, gamma, beta, running_mean, running_var, num_batches,
-                momentum: float = 0.1, eps: float = 1e-5):
+                momentum: float = 0.1, eps: float = 1e-5, conv_bias: Optional[torch.Tensor] = None):
+    """``conv_bias``: the statistics are those of the convolution WITHOUT its bias (which the caller did not add: it
+    cancels behind a train-mode BatchNorm); the running mean is kept for conv + bias, as the reference's layers do."""
     _, C, nblk = stat.shape                  # channel-major partial sums [2][C][producer workgroups]
     dev = stat.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-    rc = _L().s2s_bn_finalize(_f32(stat), nblk, C, count, _f32(gamma), _f32(beta), _f32(running_mean),
-                              _f32(running_var), 0 if num_batches is None else num_batches.data_ptr(), momentum, eps,
-                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    rc = _L().s2s_bn_finalize_b(_f32(stat), nblk, C, count, _f32(gamma), _f32(beta), _f32(running_mean),
+                                _f32(running_var), 0 if num_batches is None else num_batches.data_ptr(), momentum, eps,
+                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                _f32(conv_bias), _stream())
     _native.check(rc, "bn_finalize")
     return out
 

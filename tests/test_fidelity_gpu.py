@@ -60,7 +60,8 @@ def test_bf16_mode_trains_like_the_fp32_mode():
           f"bf16 {drop['bf16']:.3f}; held-out eval loss fp32 {held['fp32']:.5f}, bf16 {held['bf16']:.5f}")
     assert drop["fp32"] < 0.35 and drop["bf16"] < 0.35                  # both runs learn the mapping
     assert band < 0.10                                                  # curves within 10 % of each other, window by window
-    assert abs(held["bf16"] - held["fp32"]) < 0.15 * held["fp32"]       # and generalise alike
+    # and generalise alike: the bf16 run may not be more than 15 % worse on held-out data (nor implausibly better)
+    assert held["bf16"] < 1.15 * held["fp32"] and held["bf16"] > 0.7 * held["fp32"]
 
 
 def test_bf16_mode_trains_like_the_fp32_mode_at_production_width():

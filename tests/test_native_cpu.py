@@ -33,7 +33,7 @@ def test_host_side_validation_returns_status_codes_without_a_gpu():
                                                       1, 4, 4, cout, None)
     assert conv(12, 16, ok) == -1 and conv(8, 12, ok) == -1 and conv(16, 8, ok) == -1
     assert conv(8, 8, ctypes.c_void_p(4096 + 8)) == -2
-    assert lib.s2s_conv3x3_stat_blocks(0, 16, 256, 256, 64) == 16 * 32 * 8
+    assert lib.s2s_conv3x3_stat_blocks(0, 16, 256, 256, 64) == 16 * 32 * 8 * 4      # (tile, wave row) rows: 8x32x64 tile, 4 x 1 waves
     assert lib.s2s_conv3x3_stat_blocks(1, 16, 256, 256, 64) == 16 * 64 * 8
     assert lib.s2s_conv3x3_stat_blocks(7, 1, 8, 8, 8) == -3
     assert lib.s2s_conv3x3_wgrad_splits(0, 16, 256, 256, 64, 64) >= 1
@@ -135,7 +135,7 @@ def test_product_library_has_no_result_changing_switches():
     assert "S2S_CONV_DMA" not in envs, envs.get("S2S_CONV_DMA")
     # what remains is result-preserving (tile choice, workgroup order, split counts, equivalent kernels): each is either
     # exercised by tests/test_env_variants_gpu.py or changes launch geometry only
-    allowed = {"S2S_CONV_DBG", "S2S_CONV_CFG", "S2S_CONV_EPI", "S2S_CONV_NS", "S2S_CONV_XCD", "S2S_FLAT_NS", "S2S_WGRAD_XCD", "S2S_WGRAD_KH", "S2S_WGRAD_MFMA",
+    allowed = {"S2S_CONV_DBG", "S2S_CONV_CFG", "S2S_CONV_EPI", "S2S_CONV_NS", "S2S_CONV_PERS", "S2S_CONV_PERS_WGS", "S2S_CONV_XCD", "S2S_FLAT_NS", "S2S_WGRAD_XCD", "S2S_WGRAD_KH", "S2S_WGRAD_MFMA",
                "S2S_WGRAD_BLOCKS", "S2S_WGRAD_CAP", "S2S_WGRAD_DMA", "S2S_STEM_WGRAD_BLOCKS", "S2S_HEAD_LANES",
                "S2S_BN_DBIAS_SUM", "S2S_BN_REV", "S2S_UP_BWD_WIN"}
     assert set(envs) <= allowed, set(envs) - allowed
