@@ -1,13 +1,15 @@
 """Summarise rocprofv3 --pmc SQ / GRBM passes (scripts/profile_round.sh: <out>/pmc_sq1, pmc_sq2 and, for the pix2pix
 step, p2p_pmc_sq1) into profiles/<tag>_sq_counters.json: per kernel group the per-launch sums, the wave-cycle split
-(issuing / issue-stalled / parked) and a NON-SATURATED matrix-pipe utilisation from the MFMA instruction count:
+(issuing / issue-stalled / parked) and the matrix-pipe utilisation:
 
-    mfma_util_at_clock = SQ_INSTS_MFMA * 16 cycles / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
-    mfma_flops        = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512
+    mfma_util_at_clock = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+    mfma_flops         = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512
 
-(v_mfma_f32_16x16x32_bf16 holds a SIMD's matrix pipe for 16 cycles, MI355X_MICROARCH.md cycle constants; GRBM_GUI_ACTIVE
-is reported summed over the 8 XCDs.  SQ_VALU_MFMA_BUSY_CYCLES read a saturated, identical value for every kernel in round
-2 and is kept only for reference.)"""
+SQ_VALU_MFMA_BUSY_CYCLES is the sum over the SIMDs of the cycles their matrix pipe was held: it equals SQ_INSTS_MFMA x 16
+for v_mfma_f32_16x16x32_bf16 and x 32 for 32x32x16 (checked here), i.e. MOPS / 2.  Round 2 read it as "saturated" because
+the forward / data-gradient kernel and the weight-gradient kernel showed the SAME value per launch: they do -- both groups
+average the same 104.6 GFLOP per launch over the same 17 layers.  GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; the
+quotient by the launch duration is the clock the chip held (it reads high on launches well under 0.3 ms)."""
 import csv, json, os, sys
 from collections import defaultdict
 
@@ -42,9 +44,10 @@ def collect(dirs):
     return acc
 
 
-out = {"note": __doc__.split("\n\n")[0].replace("\n", " ")}
+out = {"note": " ".join(__doc__.split())}
 for which, dirs in (("cfm", ["pmc_sq1", "pmc_sq2"]), ("p2p", ["p2p_pmc_sq1"])):
     acc = collect(dirs)
+    ndirs_with_dur = sum(1 for d in dirs if os.path.isdir(os.path.join(src, d)))
     for label, needles in GROUPS[which].items():
         ks = [k for k in acc if any(n in k for n in needles)]
         if not ks:
@@ -65,13 +68,15 @@ for which, dirs in (("cfm", ["pmc_sq1", "pmc_sq2"]), ("p2p", ["p2p_pmc_sq1"])):
             e["wave_cycles_split"] = {"active_inst": round(tot["SQ_ACTIVE_INST_ANY"] / wc, 3),
                                       "wait_inst": round(tot["SQ_WAIT_INST_ANY"] / wc, 3),
                                       "wait_any": round(tot["SQ_WAIT_ANY"] / wc, 3)}
-        if tot.get("SQ_INSTS_MFMA") and tot.get("GRBM_GUI_ACTIVE"):
+        if tot.get("SQ_VALU_MFMA_BUSY_CYCLES") and tot.get("GRBM_GUI_ACTIVE"):
             cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
-            e["mfma_util_at_clock"] = round(tot["SQ_INSTS_MFMA"] * 16.0 / (cyc * 1024.0), 4)
+            e["mfma_util_at_clock"] = round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
+            e["mfma_busy_cycles_per_instruction"] = round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / tot["SQ_INSTS_MFMA"], 2)
             if tot.get("_dur_ns"):
-                e["avg_launch_us_under_pmc"] = round(tot["_dur_ns"] / n / 1e3, 2)
-                e["clock_ghz_from_grbm"] = round(cyc / tot["_dur_ns"], 3)
-                e["mfma_tflops_from_counters"] = round(tot.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / tot["_dur_ns"] / 1e3, 1)
+                dur = tot["_dur_ns"] / ndirs_with_dur
+                e["avg_launch_us_under_pmc"] = round(dur / n / 1e3, 2)
+                e["clock_ghz_from_grbm"] = round(cyc / dur, 3)
+                e["mfma_tflops_from_counters"] = round(tot.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / dur / 1e3, 1)
                 e["mfma_frac_of_2.5PF"] = round(e["mfma_tflops_from_counters"] / 2500.0, 4)
         if tot.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"], 4)
