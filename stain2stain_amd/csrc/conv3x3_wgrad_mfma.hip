@@ -253,16 +253,10 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
 //         one staged dY tile and one full halo, a wave holds 48 accumulators (three waves per SIMD), and the machine is
 //         filled by 256 workgroups instead of 512 -- half the pixel splits, i.e. half the partial-slab bytes written at
 //         the end of the kernel (when every workgroup stores at once and the MFMAs idle) and read back by the reduce.
-// TEAMS = 2 (round 3, NT = 9): one 8-wave workgroup per CU instead of two 4-wave ones.  Its two 4-wave teams work on
-//         the SAME (co, ci) tile with their own LDS buffers and their own pixel tiles (split 2 bz + team of 2 gridDim.z),
-//         in lockstep through the shared barrier; at the end team 1 hands its 144 accumulators per lane to team 0 through
-//         the (then free) LDS and ONE partial slab leaves the workgroup.  Same occupancy (two waves per SIMD), half the
-//         slabs: the 75 MB of partial sums a launch wrote -- and the fold read back -- whatever the layer become 37 MB.
-template <int TH, int TW, int NT, bool KHW = false, int TEAMS = 1>
-__global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
+template <int TH, int TW, int NT, bool KHW = false>
+__global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
   using T = bf16_t;
   static_assert(!KHW || NT == 3, "teams own one kernel row each");
-  static_assert(TEAMS == 1 || (TEAMS == 2 && NT == 9 && !KHW), "pixel teams exist for the nine-tap form");
   constexpr int NW = KHW ? 12 : 4;
   constexpr int NPX = TH * TW;                             // 128
   constexpr int HW_ = TW + 2, HR = (NT == 9 || KHW) ? TH + 2 : TH, HALO = HR * HW_;
@@ -281,11 +275,8 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
   const T* __restrict__ x1 = static_cast<const T*>(a.x1);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int team = TEAMS == 2 ? (wave8 >> 2) : 0;
-  const int wave = TEAMS == 2 ? (wave8 & 3) : wave8;       // wave inside its team (DMA group owner, (co, ci) quadrant)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = (wave & 3) >> 1, wci = wave & 1;
-  char* const tsm = smem + team * (2 * BUF);               // the team's two staging buffers
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (a.xcd) {     // workgroups go to the 8 XCDs round-robin by linear id: XCD x takes logical ids [x N/8, (x+1) N/8)
     const unsigned L = bx + gridDim.x * (by + gridDim.y * bz), per = gridDim.x * gridDim.y * gridDim.z / 8;
@@ -298,8 +289,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
   const int drow = lane >> 2, dslot = lane & 3;
   const int kh0 = (NT == 9) ? 0 : KHW ? (wave >> 2) : (int)(bz % 3);
   const int khx = KHW ? 0 : kh0;                            // first kernel row of the staged halo
-  const int zslab = (NT == 9 || KHW) ? (int)bz : (int)(bz / 3);      // partial slab this workgroup writes
-  const int zsplit = zslab * TEAMS + team, zstride = a.S * TEAMS;    // pixel tiles zsplit, zsplit + zstride, ...
+  const int zsplit = (NT == 9 || KHW) ? (int)bz : (int)(bz / 3);
 
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
@@ -349,7 +339,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
     const int y0 = ty * TH, xs = tx * TW;
     const long pixbase = (long)(img * a.H + y0) * a.W + xs;           // wave-uniform
     const bool interior = y0 >= 1 && y0 + TH + 1 <= a.H && xs >= 1 && xs + TW + 1 <= a.W;
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)tsm + buf * BUF;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
     if (interior) {
 #pragma unroll
       for (int j = 0; j < DYG; ++j) {
@@ -388,35 +378,20 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
   if (tile < a.ntiles) dma_tile(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // Both teams run the same number of iterations (the barrier is the workgroup's).  A team past its last tile keeps
-  // multiplying: its next dY image is fetched from the zero page, so the products vanish against whatever (finite)
-  // halo its buffer still holds -- no branch around the MFMA block, which would cost a second accumulator set.
-  const int niter = (a.ntiles - zslab * TEAMS + zstride - 1) / zstride;
-  auto dma_zero_dy = [&](int buf) {
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)tsm + buf * BUF;
+  for (; tile < a.ntiles; tile += a.S) {
+    if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);   // lands during the MFMAs below
+    const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off + (KHW ? kh0 * (HW_ * 64) : 0);
 #pragma unroll
-    for (int j = 0; j < DYG; ++j) {
-      if (KHW && wave + NW * j >= DYGRP) break;
-      dma16_asm((const void*)g_wgrad_zero_page, __builtin_amdgcn_readfirstlane(base + (wave + NW * j) * 1024));
-    }
-  };
-  for (int it = 0; it < niter; ++it, tile += zstride) {
-    if (tile + zstride < a.ntiles) dma_tile(tile + zstride, buf ^ 1);   // lands during the MFMAs below
-    else if (TEAMS == 2 && it + 1 < niter) dma_zero_dy(buf ^ 1);
-    {
-      const char* const Ahi = tsm + buf * BUF + wco * (NPX * 64) + frag_off;
-      const char* const Bhi = tsm + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off + (KHW ? kh0 * (HW_ * 64) : 0);
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const int py = m0 / TW, px = m0 - py * TW;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int m0 = ks * 16;
-        const int py = m0 / TW, px = m0 - py * TW;
-        const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int hoff = ((py + t / 3) * HW_ + px + t % 3) * 64;
-          const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
-        }
+      for (int t = 0; t < NT; ++t) {
+        const int hoff = ((py + t / 3) * HW_ + px + t % 3) * 64;
+        const bf16x8 bfr = tr_frag(Bhi + hoff, 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
       }
     }
     // every MFMA (hence every LDS read of this buffer) is issued before the barrier: the next iteration's DMA
@@ -425,30 +400,6 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     buf ^= 1;
-  }
-
-  if constexpr (TEAMS == 2) {
-    // team 1 -> team 0 through LDS: float [NT * 16][256 lanes] (147 KB of the 160 KB the staging buffers held)
-    float* const xch = reinterpret_cast<float*>(smem);
-    const int l256 = tid & 255;
-    if (team == 1) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xch[(t * 16 + j) * 256 + l256] = acc[t][j];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-    if (team == 1) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int j4 = 0; j4 < 16; j4 += 4) {
-#pragma unroll
-        for (int j = j4; j < j4 + 4; ++j) acc[t][j] += xch[(t * 16 + j) * 256 + l256];
-        __builtin_amdgcn_sched_barrier(0);      // four reads in flight at a time: the accumulators fill the register file
-      }
   }
 
   const int r = lane & 31, h = lane >> 5;
@@ -460,7 +411,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256 * TEAMS, (KHW || TEAMS == 2) ? 1 : 
     for (int j = 0; j < 16; ++j) {
       const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
       if (co < a.Cout && ci < cin)
-        a.part[(((long)zslab * 9 + tap) * a.Cout + co) * cin + ci] = acc[t][j];
+        a.part[(((long)zsplit * 9 + tap) * a.Cout + co) * cin + ci] = acc[t][j];
     }
   }
 }
@@ -701,22 +652,21 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   return S2S_OK;
 }
 
-template <int TH, int TW, int NT, bool KHW = false, int TEAMS = 1>
+template <int TH, int TW, int NT, bool KHW = false>
 int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
   constexpr int XROWS = (((NT == 9 || KHW) ? TH + 2 : TH) * (TW + 2) + 31) / 32 * 32;
-  constexpr int lds = TEAMS * 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
-  static_assert(lds <= 160 * 1024 && (TEAMS == 1 || 9 * 16 * 256 * 4 <= lds), "LDS budget / accumulator hand-off area");
+  constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   a.ntiles = a.B * a.tilesY * a.tilesX;
-  if ((long)a.S * TEAMS > a.ntiles) return S2S_ERR_SHAPE;
-  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT, KHW, TEAMS>;
+  if (a.S > a.ntiles) return S2S_ERR_SHAPE;
+  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT, KHW>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * ((NT == 9 || KHW) ? 1 : 3));
   static const int xcd_aware = [] { const char* e = getenv("S2S_WGRAD_XCD"); return e ? atoi(e) : 1; }();
   a.xcd = xcd_aware && ((long)grid.x * grid.y * grid.z) % 8 == 0;
-  hipLaunchKernelGGL(kern, grid, dim3(KHW ? 768 : 256 * TEAMS), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(KHW ? 768 : 256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -741,8 +691,7 @@ int launch_wgrad_dma_m16(WgradArgs& a, hipStream_t s) {
 }
 
 // how the nine taps are spread (bf16 DMA kernel): 0 = nine per wave, 1 = the kh rows over three workgroups, 2 = the kh
-// rows over the three 4-wave teams of a 12-wave workgroup, 4 = nine per wave in 8-wave workgroups whose two PIXEL teams
-// share one partial slab (TEAMS = 2: half the slab traffic at the same occupancy)
+// rows over the three 4-wave teams of a 12-wave workgroup
 inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
   static const int mode = [] { const char* e = getenv("S2S_WGRAD_KH"); return e ? atoi(e) : -1; }();
   if (dtype != S2S_BF16) return 0;
@@ -1355,15 +1304,14 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   const int khm = wgrad_kh_split(dtype, Cin, Cout);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (khm == 1 ? 3 : 1);
   static const int target_env = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int teams = khm == 4 ? 2 : 1;
-  const int target = target_env ? target_env : ((khm == 2 || khm == 4) ? 256 : 512);   // one 12- / 8-wave or two 4-wave workgroups per CU
+  const int target = target_env ? target_env : (khm == 2 ? 256 : 512);   // one 12-wave or two 4-wave workgroups per CU
   // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
   // slab, so the two-tile layers stop at 320 splits (a single-tile layer takes all 512)
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
-  const int cap = (cap_env ? cap_env : (mn == 1 ? 512 : 320)) / teams;   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
+  const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
   int s = target / mn;
   if (s > cap) s = cap;
-  if (s > nt / teams) s = nt / teams;
+  if (s > nt) s = nt;
   if (s < 1) s = 1;
   return s;
 }
@@ -1393,7 +1341,6 @@ extern "C" int s2s_conv3x3_wgrad_phase(int dtype, const void* dy, int lddy, int 
       case 16: rc = launch_wgrad_dma_m16<8, 16>(a, s); break;
       case 1: rc = launch_wgrad_dma<8, 16, 3>(a, s); break;
       case 2: rc = launch_wgrad_dma<8, 16, 3, true>(a, s); break;
-      case 4: rc = (2L * a.S <= wgrad_ntiles(B, H, W)) ? launch_wgrad_dma<8, 16, 9, false, 2>(a, s) : launch_wgrad_dma<8, 16, 9>(a, s); break;
       default: rc = launch_wgrad_dma<8, 16, 9>(a, s);
     }
   else if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
