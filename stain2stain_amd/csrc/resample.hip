@@ -9,6 +9,7 @@
 // Index arithmetic follows ATen's upsample_bilinear2d: scale = (in-1)/(out-1) in fp32,
 // src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), w1 = src - i0, w0 = 1 - w1.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,14 +44,20 @@ template <typename T, bool BIAS>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, int ldx,
                                                              const float* __restrict__ bias, T* __restrict__ y,
                                                              int ldy, int B, int Hin, int Win, int Hout, int Wout,
-                                                             int padT, int padL, int C) {
+                                                             int padT, int padL, int C, int band) {
   const int cp = C >> 3;
   const int Hu = 2 * Hin, Wu = 2 * Win;
   const float sh = Hu > 1 ? (float)(Hin - 1) / (float)(Hu - 1) : 0.f;
   const float sw = Wu > 1 ? (float)(Win - 1) / (float)(Wu - 1) : 0.f;
   const int PCB = rs_pcb(C), WL = 256 / PCB;
   const int pc = threadIdx.x & (PCB - 1), slot = threadIdx.x / PCB;
-  for (int row = blockIdx.x; row < B * Hout; row += gridDim.x) {
+  // A workgroup takes BANDS of `band` consecutive output rows (round 3): consecutive output rows read the same two
+  // input rows, and workgroups are dealt to the eight XCDs round-robin, so with one row per workgroup every XCD's L2
+  // fetched every input row (the counters had the launch at 1.6x its algorithmic bytes); a band keeps the shared rows
+  // in one L2.
+  const int nrows = B * Hout;
+  for (int row0 = blockIdx.x * band; row0 < nrows; row0 += gridDim.x * band)
+  for (int row = row0; row < row0 + band && row < nrows; ++row) {
     const int n = row / Hout, oy = row - n * Hout;
     const int uy = oy - padT;
     const bool row_in = uy >= 0 && uy < Hu;
@@ -253,10 +260,14 @@ extern "C" int s2s_upsample2x_bilinear_ac_fwd(int dtype, const void* x, int ldx,
     return S2S_ERR_SHAPE;                                        // 32-bit offsets inside a row
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)B * Hout;
-  const dim3 grid((unsigned)(rows < 65535 * 4 ? rows : 65535 * 4));
+  // rows per workgroup: 4 while that still leaves >= 1024 workgroups (4 per CU), else 2, else 1 (S2S_UP_BAND overrides)
+  static const int band_env = [] { const char* e = getenv("S2S_UP_BAND"); return e ? atoi(e) : 0; }();
+  const int band = band_env > 0 ? band_env : (rows >= 4096 ? 4 : rows >= 2048 ? 2 : 1);
+  const long nwg = (rows + band - 1) / band;
+  const dim3 grid((unsigned)(nwg < 65535 * 4 ? nwg : 65535 * 4));
 #define S2S_UP(TT, BB)                                                                                          \
   hipLaunchKernelGGL((upsample2x_fwd_kernel<TT, BB>), grid, dim3(256), 0, s, (const TT*)x, ldx, bias_nc, (TT*)y, \
-                     ldy, B, Hin, Win, Hout, Wout, padT, padL, C)
+                     ldy, B, Hin, Win, Hout, Wout, padT, padL, C, band)
   if (dtype == S2S_BF16) { if (bias_nc) S2S_UP(bf16_t, true); else S2S_UP(bf16_t, false); }
   else if (dtype == S2S_F32) { if (bias_nc) S2S_UP(float, true); else S2S_UP(float, false); }
   else return S2S_ERR_DTYPE;
