@@ -354,6 +354,8 @@ int s2s_pack_conv4x4_batched(int dtype, const void* desc, int nlayers, long tota
  * generator's input (source tile) and the discriminator's (source | target). */
 int s2s_p2p_pack_input(int dtype, const float* a_nchw, int ca, const float* b_nchw, int cb, void* out, int ldo, int B,
                        int H, int W, void* stream);
+/* The inverse for gradients: out_nchw[n][c][p] (fp32) = in[n][p][c0 + c], in = an 8-channel NHWC image (pixel stride ldi). */
+int s2s_p2p_unpack(int dtype, const void* in, int ldi, int c0, int C, float* out_nchw, int B, int H, int W, void* stream);
 /* Generator head: fake = tanh(h[..., :C]); d_in <- [src | fake | zeros] (the discriminator's input, 8 channels);
  * fake_nchw (optional) <- fake as NCHW fp32; l1_out[0] = mean |fake - tgt|.  work: double[s2s_p2p_tanh_l1_blocks()]. */
 int s2s_p2p_tanh_l1_blocks(int B, int H, int W);
@@ -368,6 +370,11 @@ int s2s_p2p_tanh_l1_bwd(int dtype, const void* h, int ldh, const float* tgt_nchw
  * w_real * (sigmoid(z) - 1) | w_fake * sigmoid(z), 0 on the padding channels. */
 int s2s_p2p_bce_logits(int dtype, const void* z, int ldz, int n_real, float w_real, float w_fake, void* dz, int lddz,
                        float* out2, int N, int HW, void* stream);
+/* The same spread over s2s_p2p_bce_blocks(N, HW) workgroups (one workgroup's softplus / sigmoid arithmetic for a
+ * batch-64 map is 20-40 us); work: double[2 * s2s_p2p_bce_blocks(N, HW)], summed in workgroup order. */
+int s2s_p2p_bce_blocks(int N, int HW);
+int s2s_p2p_bce_logits_w(int dtype, const void* z, int ldz, int n_real, float w_real, float w_fake, void* dz, int lddz,
+                         float* out2, double* work, int N, int HW, void* stream);
 /* Backward of a LeakyReLU / ReLU without a norm in front, from its stored output a: dz = a > 0 ? g + g2 : slope * g
  * (g2 optional: the gradient wrt the ReLU'd copy); dbias (optional) (+)= per-channel sum of dz.
  * work: float[C * s2s_p2p_act_bwd_blocks()]. */

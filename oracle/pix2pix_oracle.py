@@ -1,5 +1,5 @@
 """CPU restatement of the pix2pix building blocks of SURVEY.md section 8, row a13.  TEST INFRASTRUCTURE ONLY: imported
-by tests/ (and nothing else); the product path never touches it.
+by tests/ and __graft_entry__.smoke() (and nothing else); the product path never touches it.
 
 PARITY UNPINNED with respect to the reference repository: it contains no pix2pix / PatchGAN code, no
 golden vector and no test for this row.  What pins these formulas instead is torch's own operators, which is what a
@@ -103,3 +103,38 @@ class OracleDiscriminator(torch.nn.Module):
         for k in range(2, self.n_layers + 2):
             h = F.leaky_relu(F.instance_norm(getattr(self, f"c{k}")(h)), 0.2)
         return getattr(self, f"c{self.n_layers + 2}")(h)[:, :1]
+
+
+def pix2pix_losses(G, D, src, tgt, lambda_l1: float = 100.0):
+    """One pix2pix evaluation on any pair of modules with the (x) -> fake / (a, b) -> logits signatures: (fake, loss_D,
+    loss_G) with the vanilla GAN objective (BCE with logits) + lambda * L1 -- the definition the fused HIP step
+    (stain2stain_amd.Pix2PixTrainer) is checked against."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    fake = G(src)
+    pr, pf = D(src, tgt), D(src, fake.detach())
+    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
+    pg = D(src, fake)
+    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
+    return fake, loss_d, loss_g
+
+
+def pix2pix_step(G, D, opt_g, opt_d, src, tgt, lambda_l1: float = 100.0):
+    """The G + D optimisation step of pix2pix with torch optimisers: discriminator update on (real, detached fake), then
+    the generator update through the updated discriminator.  Returns (loss_D, loss_G) as tensors."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    fake = G(src)
+    opt_d.zero_grad(set_to_none=True)
+    pr, pf = D(src, tgt), D(src, fake.detach())
+    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
+    loss_d.backward()
+    opt_d.step()
+    opt_g.zero_grad(set_to_none=True)
+    for p in D.parameters():
+        p.requires_grad_(False)
+    pg = D(src, fake)
+    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
+    loss_g.backward()
+    for p in D.parameters():
+        p.requires_grad_(True)
+    opt_g.step()
+    return loss_d.detach(), loss_g.detach()

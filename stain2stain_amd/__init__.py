@@ -13,7 +13,7 @@ from .flow_matching import (ClassConditionalFlowMatchingModule, ConditionalFlowM
                             euler_generate, euler_integrate)
 from . import checkpoint
 from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, InstanceNormLeakyReLU,
-                      PatchGANDiscriminator, Pix2PixGenerator, pix2pix_step)
+                      PatchGANDiscriminator, Pix2PixGenerator)
 from .pix2pix_engine import Pix2PixTrainer
 from .trainer import CFMTrainer
 
@@ -22,4 +22,4 @@ __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeE
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",
-           "Pix2PixGenerator", "PatchGANDiscriminator", "pix2pix_step", "Pix2PixTrainer"]
+           "Pix2PixGenerator", "PatchGANDiscriminator", "Pix2PixTrainer"]

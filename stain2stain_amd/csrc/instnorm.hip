@@ -341,6 +341,162 @@ __global__ __launch_bounds__(256) void in_small_kernel(const T* __restrict__ x, 
   }
 }
 
+// bf16 form of the above with the slice held in registers: a (sample, 64-channel) slice of <= 1024 pixels is 16 pieces
+// of 16 B per thread (512 threads: 8 channel pieces x 64 pixel lanes), so every load of the launch is issued up front
+// (full memory-level parallelism, whole 128-B lines per pixel) and the second pass needs no memory at all.  x, g and g2
+// stay in their bf16 form (4 VGPRs per piece); the arithmetic is the one of in_small_kernel.
+constexpr int IN_RCG = 64;
+constexpr int IN_RIT = IN_SMALL_HW / 64;
+
+__device__ __forceinline__ f32x8 cvt8(const bf16x8& a) {
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
+
+template <bool BWD, bool G2>
+__global__ __launch_bounds__(512) void in_small_res_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ g,
+                                                           int ldg, const bf16_t* __restrict__ g2, int ldg2,
+                                                           bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ y2, int ldy2,
+                                                           float* __restrict__ stats, int B, int HW, int C, float eps,
+                                                           float slope) {
+  const int pc = threadIdx.x & 7, wl = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, c8 = blockIdx.x * IN_RCG + pc * 8;
+  const bool live = c8 < C;
+  const long BC = (long)B * C, o = (long)n * C + c8;
+  const bf16_t* const xb = x + (long)n * HW * ldx + c8;
+  __shared__ double red[2][8][IN_RCG];
+  __shared__ float fin[4][IN_RCG];
+  bf16x8 xr[IN_RIT], gr[BWD ? IN_RIT : 1];     // g2 is re-read in both passes (x, g and g2 resident would spill)
+  float mu[8], is[8], sc[8], sh[8], shift0[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) shift0[k] = 0.f;
+  if (live) {
+#pragma unroll
+    for (int it = 0; it < IN_RIT; ++it) {
+      const int p = wl + it * 64;
+      if (p < HW) {
+        xr[it] = *reinterpret_cast<const bf16x8*>(xb + (long)p * ldx);
+        if (BWD) gr[it] = *reinterpret_cast<const bf16x8*>(g + ((long)n * HW + p) * ldg + c8);
+      }
+    }
+    if (BWD) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mu[k] = stats[o + k]; is[k] = stats[BC + o + k]; sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
+    } else {
+      const f32x8 v0 = load8(xb);                       // the shift of in_small_kernel: the channel's first pixel
+#pragma unroll
+      for (int k = 0; k < 8; ++k) shift0[k] = v0.v[k];
+    }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  if (live) {
+#pragma unroll
+    for (int it = 0; it < IN_RIT; ++it) {
+      if (wl + it * 64 < HW) {
+        const f32x8 v = cvt8(xr[it]);
+        if (BWD) {
+          const f32x8 gv = cvt8(gr[it]);
+          bf16x8 hr;
+          if (G2) hr = *reinterpret_cast<const bf16x8*>(g2 + ((long)n * HW + wl + it * 64) * ldg2 + c8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float gw = G2 ? (float)hr[k] : 0.f;
+            const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw : slope * gv.v[k];
+            s1[k] += dz;
+            s2[k] = fmaf(dz, (v.v[k] - mu[k]) * is[k], s2[k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float d = v.v[k] - shift0[k]; s1[k] += d; s2[k] = fmaf(d, d, s2[k]); }
+        }
+      }
+    }
+  }
+  // the 8 pixel lanes of a wave that share a channel piece, then the 8 waves through LDS
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double a = (double)s1[k], b = (double)s2[k];
+#pragma unroll
+    for (int m = 8; m <= 32; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+    if ((threadIdx.x & 63) < 8) { red[0][wave][pc * 8 + k] = a; red[1][wave][pc * 8 + k] = b; }
+  }
+  if (!BWD && wl == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fin[0][pc * 8 + k] = shift0[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < IN_RCG) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { a += red[0][r][threadIdx.x]; b += red[1][r][threadIdx.x]; }
+    const int c = blockIdx.x * IN_RCG + threadIdx.x;
+    if (BWD) {
+      fin[0][threadIdx.x] = (float)a / (float)HW;
+      fin[1][threadIdx.x] = (float)b / (float)HW;
+    } else {
+      const double ms = a / (double)HW;
+      double var = b / (double)HW - ms * ms;
+      if (var < 0.0) var = 0.0;
+      const double mean = ms + (double)fin[0][threadIdx.x];
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      fin[0][threadIdx.x] = (float)mean; fin[1][threadIdx.x] = invstd;
+      fin[2][threadIdx.x] = invstd; fin[3][threadIdx.x] = -(float)mean * invstd;
+      if (c < C) {
+        const long i = (long)n * C + c;
+        stats[i] = (float)mean; stats[BC + i] = invstd; stats[2 * BC + i] = invstd; stats[3 * BC + i] = -(float)mean * invstd;
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  if (BWD) {
+    float k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { k1[k] = fin[0][pc * 8 + k]; k2[k] = fin[1][pc * 8 + k]; }
+#pragma unroll
+    for (int it = 0; it < IN_RIT; ++it) {
+      const int p = wl + it * 64;
+      if (p < HW) {
+        const f32x8 v = cvt8(xr[it]), gv = cvt8(gr[it]);
+        bf16x8 hr;
+        if (G2) hr = *reinterpret_cast<const bf16x8*>(g2 + ((long)n * HW + p) * ldg2 + c8);
+        f32x8 o8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float gw = G2 ? (float)hr[k] : 0.f;
+          const float dz = fmaf(v.v[k], sc[k], sh[k]) > 0.f ? gv.v[k] + gw : slope * gv.v[k];
+          o8.v[k] = sc[k] * (dz - k1[k] - ((v.v[k] - mu[k]) * is[k]) * k2[k]);
+        }
+        store8(y + ((long)n * HW + p) * ldy + c8, o8);
+      }
+    }
+  } else {
+    float fs[8], fh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { fs[k] = fin[2][pc * 8 + k]; fh[k] = fin[3][pc * 8 + k]; }
+#pragma unroll
+    for (int it = 0; it < IN_RIT; ++it) {
+      const int p = wl + it * 64;
+      if (p < HW) {
+        const f32x8 v = cvt8(xr[it]);
+        f32x8 o8, r8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float z = fmaf(v.v[k], fs[k], fh[k]);
+          o8.v[k] = z > 0.f ? z : slope * z;
+          r8.v[k] = fmaxf(z, 0.f);
+        }
+        store8(y + ((long)n * HW + p) * ldy + c8, o8);
+        if (y2) store8(y2 + ((long)n * HW + p) * ldy2 + c8, r8);
+      }
+    }
+  }
+}
+
 inline int in_blocks(int B, int H, int W, int C) {
   const int pcb = in_pcb(C), wl = 256 / pcb, groups = cdiv(C / 8, pcb);
   const long hw = (long)H * W;
@@ -376,10 +532,10 @@ extern "C" int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const 
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
   if (!gamma && HW <= IN_SMALL_HW) {            // small maps: one launch (in_small_kernel)
-    const dim3 sg(cdiv(C, IN_CG), B);
+    const dim3 sg(cdiv(C, IN_CG), B), rg(cdiv(C, IN_RCG), B);
     if (dtype == S2S_BF16)
-      hipLaunchKernelGGL((in_small_kernel<bf16_t, false>), sg, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0,
-                         (const bf16_t*)nullptr, 0, (bf16_t*)y, ldy, (bf16_t*)y2, ldy2, stats, B, HW, C, eps, slope);
+      hipLaunchKernelGGL((in_small_res_kernel<false, false>), rg, dim3(512), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)nullptr,
+                         0, (const bf16_t*)nullptr, 0, (bf16_t*)y, ldy, (bf16_t*)y2, ldy2, stats, B, HW, C, eps, slope);
     else if (dtype == S2S_F32)
       hipLaunchKernelGGL((in_small_kernel<float, false>), sg, dim3(256), 0, s, (const float*)x, ldx, (const float*)nullptr, 0,
                          (const float*)nullptr, 0, (float*)y, ldy, (float*)y2, ldy2, stats, B, HW, C, eps, slope);
@@ -421,10 +577,14 @@ extern "C" int s2s_instnorm_lrelu_bwd2(int dtype, const void* g, int ldg, const 
   hipStream_t s = (hipStream_t)stream;
   const int nb = in_blocks(B, H, W, C), HW = H * W;
   if (!dgamma && HW <= IN_SMALL_HW) {           // small maps: one launch (in_small_kernel)
-    const dim3 sg(cdiv(C, IN_CG), B);
-    if (dtype == S2S_BF16)
-      hipLaunchKernelGGL((in_small_kernel<bf16_t, true>), sg, dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)g, ldg,
+    const dim3 sg(cdiv(C, IN_CG), B), rg(cdiv(C, IN_RCG), B);
+    if (dtype == S2S_BF16 && g2)
+      hipLaunchKernelGGL((in_small_res_kernel<true, true>), rg, dim3(512), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)g, ldg,
                          (const bf16_t*)g2, ldg2, (bf16_t*)dx, lddx, (bf16_t*)nullptr, 0, const_cast<float*>(stats), B, HW, C,
+                         0.f, slope);
+    else if (dtype == S2S_BF16)
+      hipLaunchKernelGGL((in_small_res_kernel<true, false>), rg, dim3(512), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)g, ldg,
+                         (const bf16_t*)nullptr, 0, (bf16_t*)dx, lddx, (bf16_t*)nullptr, 0, const_cast<float*>(stats), B, HW, C,
                          0.f, slope);
     else if (dtype == S2S_F32)
       hipLaunchKernelGGL((in_small_kernel<float, true>), sg, dim3(256), 0, s, (const float*)x, ldx, (const float*)g, ldg,

@@ -35,6 +35,20 @@ __global__ __launch_bounds__(256) void p2p_pack_kernel(const float* __restrict__
   }
 }
 
+// ---- p2p_unpack: the inverse for gradients -- out_nchw[n][c][p] = in[n][p][c0 + c] as fp32 ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void p2p_unpack_kernel(const T* __restrict__ in, int ldi, int c0, int C,
+                                                         float* __restrict__ out, int B, long HW) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / HW, p = i - n * HW;
+    const f32x8 v = load8(in + i * ldi);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if (k >= c0 && k < c0 + C) out[(n * C + (k - c0)) * HW + p] = v.v[k];
+  }
+}
+
 // ---- p2p_tanh_l1_fwd ------------------------------------------------------------------------------------------------
 // h: [B][HW][ldh] (C real channels); d_in: [B][HW][ldd] <- [src (C) | tanh(h) (C) | zeros]; fake_nchw (optional);
 // lpart[block] = sum |tanh(h) - tgt| in fp64
@@ -133,18 +147,30 @@ __global__ __launch_bounds__(1024) void p2p_bce_kernel(const T* __restrict__ z, 
                                                        T* __restrict__ dz, int lddz, float* __restrict__ out, int N, int HW) {
   const long total = (long)N * HW, nr = (long)n_real * HW;
   double a_real = 0.0, a_fake = 0.0;
-  for (long i = threadIdx.x; i < total; i += 1024) {
-    const float x = to_f32(z[i * ldz]);
-    const bool real = i < nr;
-    const float sp = fmaxf(real ? -x : x, 0.f) + log1pf(expf(-fabsf(x)));       // softplus(+-x), stable
-    const float sg = 1.f / (1.f + expf(-x));
-    if (real) a_real += (double)sp; else a_fake += (double)sp;
-    if (dz) {
-      f32x8 o;
+  constexpr int U = 8;                           // loads of U strides in flight: the loop is latency-, not bandwidth-bound
+  for (long base = threadIdx.x; base < total; base += 1024 * U) {
+    float xs[U];
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) o.v[k] = 0.f;
-      o.v[0] = real ? w_real * (sg - 1.f) : w_fake * sg;
-      store8(dz + i * lddz, o);
+    for (int u = 0; u < U; ++u) {
+      const long i = base + (long)u * 1024;
+      xs[u] = i < total ? to_f32(z[i * ldz]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + (long)u * 1024;
+      if (i >= total) break;
+      const float x = xs[u];
+      const bool real = i < nr;
+      const float sp = fmaxf(real ? -x : x, 0.f) + log1pf(expf(-fabsf(x)));       // softplus(+-x), stable
+      const float sg = 1.f / (1.f + expf(-x));
+      if (real) a_real += (double)sp; else a_fake += (double)sp;
+      if (dz) {
+        f32x8 o;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) o.v[k] = 0.f;
+        o.v[0] = real ? w_real * (sg - 1.f) : w_fake * sg;
+        store8(dz + i * lddz, o);
+      }
     }
   }
 #pragma unroll
@@ -158,6 +184,56 @@ __global__ __launch_bounds__(1024) void p2p_bce_kernel(const T* __restrict__ z, 
     out[0] = nr > 0 ? (float)(r / (double)nr) : 0.f;
     out[1] = total > nr ? (float)(f / (double)(total - nr)) : 0.f;
   }
+}
+
+// The same over many workgroups (the softplus / sigmoid arithmetic of a batch-64 PatchGAN map keeps one CU busy for
+// 20-40 us): partial sums per workgroup in part[2][gridDim.x], summed in workgroup order by p2p_bce_finish_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void p2p_bce_part_kernel(const T* __restrict__ z, int ldz, int n_real, float w_real,
+                                                           float w_fake, T* __restrict__ dz, int lddz,
+                                                           double* __restrict__ part, int N, int HW) {
+  const long total = (long)N * HW, nr = (long)n_real * HW;
+  double a_real = 0.0, a_fake = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float x = to_f32(z[i * ldz]);
+    const bool real = i < nr;
+    const float sp = fmaxf(real ? -x : x, 0.f) + log1pf(expf(-fabsf(x)));
+    const float sg = 1.f / (1.f + expf(-x));
+    if (real) a_real += (double)sp; else a_fake += (double)sp;
+    if (dz) {
+      f32x8 o;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) o.v[k] = 0.f;
+      o.v[0] = real ? w_real * (sg - 1.f) : w_fake * sg;
+      store8(dz + i * lddz, o);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a_real += __shfl_xor(a_real, m, 64); a_fake += __shfl_xor(a_fake, m, 64); }
+  __shared__ double red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a_real; red[1][threadIdx.x >> 6] = a_fake; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[gridDim.x + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(64) void p2p_bce_finish_kernel(const double* __restrict__ part, int nb, long nr, long total,
+                                                            float* __restrict__ out) {
+  double r = 0.0, f = 0.0;
+  for (int k = threadIdx.x; k < nb; k += 64) { r += part[k]; f += part[nb + k]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { r += __shfl_xor(r, m, 64); f += __shfl_xor(f, m, 64); }
+  if (threadIdx.x == 0) {
+    out[0] = nr > 0 ? (float)(r / (double)nr) : 0.f;
+    out[1] = total > nr ? (float)(f / (double)(total - nr)) : 0.f;
+  }
+}
+
+inline int bce_blocks(long total) {
+  long nb = (total + 1023) / 1024;
+  return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
 }
 
 // ---- p2p_act_bwd ----------------------------------------------------------------------------------------------------
@@ -260,6 +336,22 @@ extern "C" int s2s_p2p_pack_input(int dtype, const float* a_nchw, int ca, const 
   return S2S_OK;
 }
 
+extern "C" int s2s_p2p_unpack(int dtype, const void* in, int ldi, int c0, int C, float* out_nchw, int B, int H, int W,
+                              void* stream) {
+  if (!in || !out_nchw) return S2S_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || c0 < 0 || c0 + C > NCH || (ldi % 8) || ldi < NCH) return S2S_ERR_SHAPE;
+  if ((uintptr_t)in & 15) return S2S_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const long HW = (long)H * W;
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(p2p_unpack_kernel<bf16_t>, dim3(ew_blocks(B * HW)), dim3(256), 0, s, (const bf16_t*)in, ldi, c0, C, out_nchw, B, HW);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(p2p_unpack_kernel<float>, dim3(ew_blocks(B * HW)), dim3(256), 0, s, (const float*)in, ldi, c0, C, out_nchw, B, HW);
+  else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 extern "C" int s2s_p2p_tanh_l1_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
   long nb = ((long)B * H * W + 255) / 256;
@@ -322,6 +414,32 @@ extern "C" int s2s_p2p_bce_logits(int dtype, const void* z, int ldz, int n_real,
     hipLaunchKernelGGL(p2p_bce_kernel<float>, dim3(1), dim3(1024), 0, s, (const float*)z, ldz, n_real, w_real, w_fake,
                        (float*)dz, lddz, out2, N, HW);
   else return S2S_ERR_DTYPE;
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+extern "C" int s2s_p2p_bce_blocks(int N, int HW) {
+  if (N <= 0 || HW <= 0) return S2S_ERR_SHAPE;
+  return bce_blocks((long)N * HW);
+}
+
+// s2s_p2p_bce_logits over s2s_p2p_bce_blocks(N, HW) workgroups; work: double[2 * s2s_p2p_bce_blocks(N, HW)].
+extern "C" int s2s_p2p_bce_logits_w(int dtype, const void* z, int ldz, int n_real, float w_real, float w_fake, void* dz,
+                                    int lddz, float* out2, double* work, int N, int HW, void* stream) {
+  if (!z || !out2 || !work) return S2S_ERR_NULL;
+  if (N <= 0 || HW <= 0 || n_real < 0 || n_real > N || ldz <= 0 || (dz && ((lddz % 8) || lddz < NCH))) return S2S_ERR_SHAPE;
+  if (((uintptr_t)dz & 15) || ((uintptr_t)work & 7)) return S2S_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * HW;
+  const int nb = bce_blocks(total);
+  if (dtype == S2S_BF16)
+    hipLaunchKernelGGL(p2p_bce_part_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)z, ldz, n_real, w_real, w_fake,
+                       (bf16_t*)dz, lddz, work, N, HW);
+  else if (dtype == S2S_F32)
+    hipLaunchKernelGGL(p2p_bce_part_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)z, ldz, n_real, w_real, w_fake,
+                       (float*)dz, lddz, work, N, HW);
+  else return S2S_ERR_DTYPE;
+  hipLaunchKernelGGL(p2p_bce_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)work, nb, (long)n_real * HW, total, out2);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -28,7 +28,16 @@ def _dt(t: torch.Tensor) -> int:
     raise RuntimeError(f"stain2stain_amd: unsupported activation dtype {t.dtype}")
 
 
+# the current HIP stream's handle, ~80 times per optimisation step: torch.cuda.current_stream() builds a Stream object
+# through four layers of device-index helpers (8 us a call, a quarter of the host time of a pix2pix step); the raw getter
+# is one C call
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -1133,6 +1142,15 @@ def p2p_pack_input(a: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor
     return out
 
 
+def p2p_unpack(g: torch.Tensor, c0: int, C: int) -> torch.Tensor:
+    """NCHW fp32 [B,C,H,W] <- channels c0 .. c0+C-1 of the 8-channel NHWC image g (an input gradient)."""
+    B, H, W, _ = g.shape
+    pg, ldg = _nhwc(g)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+    _native.check(_L().s2s_p2p_unpack(_dt(g), pg, ldg, int(c0), int(C), out.data_ptr(), B, H, W, _stream()), "p2p_unpack")
+    return out
+
+
 @_timed("p2p_tanh_l1_fwd")
 def p2p_tanh_l1_fwd(h: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor, d_in: torch.Tensor,
                     fake_nchw: Optional[torch.Tensor] = None, l1_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1172,8 +1190,11 @@ def p2p_bce_logits(z: torch.Tensor, n_real: int, w_real: float, w_fake: float, w
     dz = torch.empty((N, H, W, 8), dtype=z.dtype, device=z.device) if want_grad else None
     if out is None:
         out = torch.empty((2,), dtype=torch.float32, device=z.device)
-    rc = _L().s2s_p2p_bce_logits(_dt(z), pz, ldz, int(n_real), float(w_real), float(w_fake),
-                                 0 if dz is None else dz.data_ptr(), 8, _f32(out), N, H * W, _stream())
+    nb = _L().s2s_p2p_bce_blocks(N, H * W)
+    _native.check(min(nb, 0), "p2p_bce_blocks")
+    work = _workspace(z.device, 4 * nb, "p2p_bce")            # double[2][nb]
+    rc = _L().s2s_p2p_bce_logits_w(_dt(z), pz, ldz, int(n_real), float(w_real), float(w_fake),
+                                   0 if dz is None else dz.data_ptr(), 8, _f32(out), work.data_ptr(), N, H * W, _stream())
     _native.check(rc, "p2p_bce_logits")
     return out, dz
 

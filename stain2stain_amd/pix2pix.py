@@ -324,26 +324,119 @@ class Conv4x4Stride1(_Layer4x4):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# The two networks (pix2pix "unet_256"-style generator, 70x70 PatchGAN discriminator) assembled from the layers above.
-# The convolutions and the norm + activation pairs run on the HIP kernels; what is still torch glue here - the
-# activation without a norm (first / innermost layer), the ReLU of the skip tensors, the channel concatenations, tanh,
-# the losses and the optimiser - is bandwidth-bound elementwise work waiting for its kernels.
+# The two networks (pix2pix "unet_256"-style generator, 70x70 PatchGAN discriminator).  Under autograd each network is
+# ONE node over the passes of the fused engine (pix2pix_engine.NetRunner): image packing, every convolution with its
+# activation epilogue, the norm passes that write the ReLU'd skip tensors into the concatenation buffers, tanh -- all HIP
+# kernels of this library, none of torch's (no leaky_relu / relu / cat / pad / tanh).  The optimisation step itself is
+# ``Pix2PixTrainer.step`` (pix2pix_engine.py); its torch restatement for the parity tests lives with the oracle
+# (oracle/pix2pix_oracle.py: pix2pix_losses, pix2pix_step).
 # ------------------------------------------------------------------------------------------------------------------
-def _pad_channels(x: torch.Tensor, c: int) -> torch.Tensor:
-    return x if x.shape[1] == c else torch.nn.functional.pad(x, (0, 0, 0, 0, 0, c - x.shape[1]))
+def _runner(net, precision: str):
+    from .pix2pix_engine import NetRunner
+    r = net.__dict__.get("_runner_obj")
+    if r is None or r.dtype != (torch.bfloat16 if precision == "bf16" else torch.float32):
+        r = NetRunner(net, precision)
+        net.__dict__["_runner_obj"] = r
+    r.refresh()
+    return r
+
+
+def _check_image(x: torch.Tensor, channels: int, what: str) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("stain2stain_amd: the pix2pix networks run on the GPU only (no CPU fallback)")
+    if x.dim() != 4 or x.shape[1] != channels:
+        raise ValueError(f"{what}: expected [B, {channels}, H, W], got {tuple(x.shape)}")
+    return x.detach().contiguous().float()
+
+
+class _GeneratorFn(torch.autograd.Function):
+    """fake = tanh(U-Net(x)); parameters in ``named_parameters`` order after (net, x)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        r = _runner(net, net.precision)
+        src = _check_image(x, net.in_channels, "Pix2PixGenerator")
+        g = r.g_forward(src)
+        B, _, H, W = src.shape
+        C = net.out_channels
+        fake = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+        ref = src if src.shape[1] == C else fake                 # (the kernel's L1 / D-input outputs are not used here)
+        ops.p2p_tanh_l1_fwd(g.h, ref, ref, torch.empty((B, H, W, 8), dtype=r.dtype, device=src.device), fake)
+        ctx.runner, ctx.g, ctx.net = r, g, net
+        return fake
+
+    @staticmethod
+    def backward(ctx, gfake):
+        r, g, net = ctx.runner, ctx.g, ctx.net
+        if g is None:
+            raise RuntimeError("Pix2PixGenerator: the activations of this forward pass were released by its first backward")
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("Pix2PixGenerator: no gradient with respect to the input image")
+        B, H, W, _ = g.h.shape
+        gf = gfake.contiguous().float()
+        # d(pre-tanh) = gfake * (1 - fake^2): the tanh backward kernel with the L1 term switched off and the upstream
+        # gradient in the channels where it expects the discriminator's input gradient
+        gd = ops.p2p_pack_input(gf, gf, torch.empty((B, H, W, 8), dtype=r.dtype, device=gf.device))
+        dh = ops.p2p_tanh_l1_bwd(g.h, gf, gd, 0.0)
+        r.pG.grads = r.new_grads()
+        r.g_backward(g, dh)
+        ctx.g = None
+        names = [k for k, _ in net.named_parameters()]
+        return (None, None) + tuple(r.pG.grads[k] if need else None for k, need in zip(names, ctx.needs_input_grad[2:]))
+
+
+class _DiscriminatorFn(torch.autograd.Function):
+    """logits = PatchGAN(cat(a, b)) as [B, 1, h, w] fp32; gradients for a, b and the parameters."""
+
+    @staticmethod
+    def forward(ctx, net, a, b, *params):
+        r = _runner(net, net.precision)
+        ca = a.shape[1] if a.dim() == 4 else -1
+        a32 = _check_image(a, ca, "PatchGANDiscriminator")
+        b32 = _check_image(b, net.in_channels - ca, "PatchGANDiscriminator")
+        if a32.shape[0] != b32.shape[0] or a32.shape[2:] != b32.shape[2:]:
+            raise ValueError("PatchGANDiscriminator: the two images differ in batch or size")
+        B, _, H, W = a32.shape
+        d_in = ops.p2p_pack_input(a32, b32, torch.empty((B, H, W, 8), dtype=r.dtype, device=a32.device))
+        z, saved = r.d_forward(d_in)
+        ctx.runner, ctx.saved, ctx.net, ctx.ca, ctx.cb = r, saved, net, ca, net.in_channels - ca
+        return ops.p2p_unpack(z, 0, 1)
+
+    @staticmethod
+    def backward(ctx, gz):
+        r, net = ctx.runner, ctx.net
+        if ctx.saved is None:
+            raise RuntimeError("PatchGANDiscriminator: the activations of this forward pass were released by its first backward")
+        gz = gz.contiguous().float()
+        B, _, h, w = gz.shape
+        dz = ops.p2p_pack_input(gz, None, torch.empty((B, h, w, 8), dtype=r.dtype, device=gz.device))
+        want_w = any(ctx.needs_input_grad[3:])
+        need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if want_w:
+            r.pD.grads = r.new_grads()
+        gd = r.d_backward(ctx.saved, dz, want_w=want_w, need_input_grad=need_x)
+        ctx.saved = None
+        ga = ops.p2p_unpack(gd, 0, ctx.ca) if ctx.needs_input_grad[1] else None
+        gb = ops.p2p_unpack(gd, ctx.ca, ctx.cb) if ctx.needs_input_grad[2] else None
+        names = [k for k, _ in net.named_parameters()]
+        return (None, ga, gb) + tuple(r.pD.grads[k] if need else None for k, need in zip(names, ctx.needs_input_grad[3:]))
 
 
 class Pix2PixGenerator(nn.Module):
     """U-Net generator: ``num_downs`` 4x4 stride-2 convolutions down to 1x1 (8 for 256x256 tiles) and the mirrored
     transposed convolutions with skip connections; LeakyReLU(0.2) / InstanceNorm on the way down, ReLU / InstanceNorm
-    on the way up, tanh at the end.  Channel plan ngf * (1, 2, 4, 8, 8, ...)."""
+    on the way up, tanh at the end.  Channel plan ngf * (1, 2, 4, 8, 8, ...).  ``precision``: "bf16" or "fp32" (the
+    three-way-split parity mode) for the module's own ``forward``; ``Pix2PixTrainer`` takes its own."""
 
-    def __init__(self, in_channels: int = 3, out_channels: int = 3, ngf: int = 64, num_downs: int = 8):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, ngf: int = 64, num_downs: int = 8,
+                 precision: str = "bf16"):
         super().__init__()
         if num_downs < 2:                 # (2 = BASELINE.json configs[0]'s "2-level U-Net": outermost + innermost layer)
             raise ValueError("num_downs >= 2")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
         ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]
-        self.in_channels, self.out_channels = in_channels, out_channels
+        self.in_channels, self.out_channels, self.precision = in_channels, out_channels, precision
         self.downs = nn.ModuleList([Conv4x4Stride2(8 if i == 0 else ch[i - 1], ch[i]) for i in range(num_downs)])
         self.down_norms = nn.ModuleList([InstanceNormLeakyReLU(ch[i], negative_slope=0.2) for i in range(1, num_downs - 1)])
         ups, norms = [], []
@@ -356,21 +449,8 @@ class Pix2PixGenerator(nn.Module):
         self.ups, self.up_norms = nn.ModuleList(ups), nn.ModuleList(norms)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        n = len(self.downs)
-        acts = []
-        h = self.downs[0](_pad_channels(x, 8))
-        h = torch.nn.functional.leaky_relu(h, 0.2)
-        acts.append(h)
-        for i in range(1, n - 1):
-            h = self.down_norms[i - 1](self.downs[i](h))
-            acts.append(h)
-        h = torch.relu(self.downs[n - 1](h))                       # innermost: no norm
-        for j, up in enumerate(self.ups):
-            h = up(h)
-            if j < n - 1:
-                h = self.up_norms[j](h)
-                h = torch.cat([torch.relu(acts[n - 2 - j]), h], 1)
-        return torch.tanh(h[:, :self.out_channels].float())
+        """x [B, in_channels, H, W] -> tanh output [B, out_channels, H, W] (fp32); differentiable in the parameters."""
+        return _GeneratorFn.apply(self, x, *self.parameters())
 
 
 class PatchGANDiscriminator(nn.Module):
@@ -380,11 +460,15 @@ class PatchGANDiscriminator(nn.Module):
     ``c1`` ... ``c5``, norms ``n2`` ... ``n4``); ``n_layers = 1`` is BASELINE.json configs[0]'s "1-layer PatchGAN"
     (C64 - C128 - C1: ``c1``, ``c2`` / ``n2``, ``c3``)."""
 
-    def __init__(self, in_channels: int = 6, ndf: int = 64, n_layers: int = 3):
+    def __init__(self, in_channels: int = 6, ndf: int = 64, n_layers: int = 3, precision: str = "bf16"):
         super().__init__()
         if n_layers < 1:
             raise ValueError("n_layers >= 1")
-        self.n_layers = n_layers
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if not 2 <= in_channels <= 8:
+            raise ValueError("in_channels: 2 ... 8 (the two images together, padded to 8 channels)")
+        self.n_layers, self.in_channels, self.precision = n_layers, in_channels, precision
         self.c1 = Conv4x4Stride2(8, ndf)
         kinds = ["s2"]
         cin = ndf
@@ -404,41 +488,6 @@ class PatchGANDiscriminator(nn.Module):
         return [(f"c{k + 1}", kind, getattr(self, f"c{k + 1}")) for k, kind in enumerate(self.layer_kinds)]
 
     def forward(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        K = len(self.layer_kinds)
-        h = torch.nn.functional.leaky_relu(self.c1(_pad_channels(torch.cat([a, b], 1), 8)), 0.2)
-        for k in range(2, K):
-            h = getattr(self, f"n{k}")(getattr(self, f"c{k}")(h))
-        return getattr(self, f"c{K}")(h)[:, :1].float()
-
-
-def pix2pix_losses(G: nn.Module, D: nn.Module, src: torch.Tensor, tgt: torch.Tensor, lambda_l1: float = 100.0):
-    """One pix2pix evaluation: (fake, loss_D, loss_G) with the vanilla GAN objective (BCE with logits) + lambda * L1."""
-    bce = torch.nn.functional.binary_cross_entropy_with_logits
-    fake = G(src)
-    pr, pf = D(src, tgt), D(src, fake.detach())
-    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
-    pg = D(src, fake)
-    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
-    return fake, loss_d, loss_g
-
-
-def pix2pix_step(G, D, opt_g, opt_d, src, tgt, lambda_l1: float = 100.0):
-    """The G + D optimisation step of pix2pix: discriminator update on (real, detached fake), then generator update
-    through the discriminator.  Returns (loss_D, loss_G) as tensors."""
-    bce = torch.nn.functional.binary_cross_entropy_with_logits
-    fake = G(src)
-    opt_d.zero_grad(set_to_none=True)
-    pr, pf = D(src, tgt), D(src, fake.detach())
-    loss_d = 0.5 * (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf)))
-    loss_d.backward()
-    opt_d.step()
-    opt_g.zero_grad(set_to_none=True)
-    for p in D.parameters():
-        p.requires_grad_(False)
-    pg = D(src, fake)
-    loss_g = bce(pg, torch.ones_like(pg)) + lambda_l1 * (fake - tgt).abs().mean()
-    loss_g.backward()
-    for p in D.parameters():
-        p.requires_grad_(True)
-    opt_g.step()
-    return loss_d.detach(), loss_g.detach()
+        """a, b: the two images (NCHW, ``in_channels`` together) -> logits [B, 1, h, w] (fp32); differentiable in a, b and
+        the parameters."""
+        return _DiscriminatorFn.apply(self, a, b, *self.parameters())

@@ -46,6 +46,7 @@ class FlatParams:
                  max_bucket_mb: float = 16.0, sharded: bool = False):
         dev = groups[0][0][1].device
         sizes, offs, off = [], {}, 0
+        self.group_range: List[Tuple[int, int]] = []
         for g in groups:
             start = off
             for name, p in g:
@@ -53,6 +54,7 @@ class FlatParams:
                 off += (p.numel() + 7) // 8 * 8            # 32-byte aligned views
             off = (off + ALIGN - 1) // ALIGN * ALIGN       # groups (layers) divide into aligned shards for <= 8 ranks
             sizes.append(off - start)
+            self.group_range.append((start, off))
         self.p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -87,6 +89,18 @@ class FlatParams:
             else:
                 ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], hyper_dev)
         self.bucketer.all_gather(self.p)
+
+    def adam_group(self, group: int, lr: float, betas: Tuple[float, float], eps: float, weight_decay: float,
+                   hyper_dev: Optional[torch.Tensor] = None) -> None:
+        """Adam on the slice of parameter group ``group`` alone (the step counter is the caller's: ``begin_step``), for
+        the update-in-backward of a trainer without a gradient exchange.  Adam is element-wise: the slices of all groups
+        together are exactly ``adam``."""
+        lo, hi = self.group_range[group]
+        if hyper_dev is None:
+            ops.adam_step_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.step_count, lr, betas[0],
+                           betas[1], eps, weight_decay, self.bucketer.grad_scale)
+        else:
+            ops.adam_step_dev_(self.p[lo:hi], self.g[lo:hi], self.m[lo:hi], self.v[lo:hi], hyper_dev)
 
     def state_dict(self) -> Dict:
         """Adam state by parameter name.  Sharded optimiser: the moments are all-gathered first (a collective: every rank
@@ -148,12 +162,21 @@ class _Packer:
             l.wd = torch.empty(((o + 31) // 32, taps, K, 32), dtype=dtype, device=w.device)
             rows.append([w.data_ptr(), l.wf.data_ptr(), l.wd.data_ptr(), o, c, 1 if stride == 2 else 0, start])
             start += L.s2s_pack_conv4x4_blocks(o, c, stride)
-        self.desc = torch.tensor(rows, dtype=torch.int64, device=layers[0].weight.device)
+        dev = layers[0].weight.device
+        self.desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.total = start
+        # one-layer descriptors (first block 0) for the update-in-backward
+        firsts = [r[6] for r in rows] + [start]
+        self.one = {l.name: (torch.tensor([r[:6] + [0]], dtype=torch.int64, device=dev), firsts[i + 1] - firsts[i])
+                    for i, (l, r) in enumerate(zip(layers, rows))}
         self.repack()
 
     def repack(self) -> None:
         ops.pack_conv4x4_batched(self.desc, self.total, self.dtype)
+
+    def repack_layer(self, name: str) -> None:
+        desc, total = self.one[name]
+        ops.pack_conv4x4_batched(desc, total, self.dtype)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -262,6 +285,12 @@ class Pix2PixTrainer:
         # S2S_WGRAD_STREAM=0 keeps everything on one stream, overlap_wgrad = False does so for a single step
         self._side = ops.side_stream_for(dev)
         self.overlap_wgrad = True
+        # generator update inside its backward pass (S2S_P2P_OPT_IN_BWD=1): a layer's Adam slice + repack go onto the side
+        # stream right behind its weight gradient instead of 0.4 ms of bandwidth-bound work (54 M parameters) at the end of
+        # the step.  Element-wise identical to the end-of-step update; only without a gradient exchange.  Off by default:
+        # measured 3.90 vs 3.86 ms/step -- the step is bound by total GPU work, not by the compute stream's length (the
+        # overlapped Adam slows the convolutions it overlaps by as much as it saves), and it costs 30 more launches.
+        self.opt_in_backward = os.environ.get("S2S_P2P_OPT_IN_BWD", "0") == "1"
         self.last: Dict[str, torch.Tensor] = {}
         self.graph = graph
         self._captured, self._warm_key = None, None
@@ -333,10 +362,25 @@ class Pix2PixTrainer:
                 ctx.h = hraw
         return ctx
 
-    def g_backward(self, ctx: _GCtx, dh: torch.Tensor) -> None:
-        """dh: gradient wrt the pre-tanh output.  Gradients go to the flat buffer; buckets are launched as they close."""
+    def _update_group(self, grp: int, l: _Layer, hyper_dev) -> None:
+        """Adam + repack of generator layer ``l`` (parameter group ``grp``), behind its gradients on both streams."""
+        side = engine.side_stream
+        if side is None:
+            self.pG.adam_group(grp, self.lr, self.betas, self.eps, self.wd, hyper_dev)
+            self.packG.repack_layer(l.name)
+            return
+        side.wait_stream(torch.cuda.current_stream())     # bias gradient; the data gradient that reads the packed operand
+        with torch.cuda.stream(side):
+            self.pG.adam_group(grp, self.lr, self.betas, self.eps, self.wd, hyper_dev)
+            self.packG.repack_layer(l.name)
+
+    def g_backward(self, ctx: _GCtx, dh: torch.Tensor, update: bool = False, hyper_dev=None) -> None:
+        """dh: gradient wrt the pre-tanh output.  Gradients go to the flat buffer; buckets are launched as they close.
+        ``update``: every layer's Adam step + repack follow its gradients at once (see ``opt_in_backward``)."""
         n, gr, bk = self.n, self.pG.grads, self.pG.bucketer
         bk.start_step()
+        if update and hyper_dev is None:
+            self.pG.step_count += 1
         ch = [l.conv_out for l in self.g_down]
         grp = 0
         g = dh
@@ -355,7 +399,10 @@ class Pix2PixTrainer:
                 g = dx
             else:
                 dcat[j] = dx
-            self._mark(self.pG, grp); grp += 1
+            self._mark(self.pG, grp)
+            if update:
+                self._update_group(grp, l, hyper_dev)
+            grp += 1
         for i in range(n - 1, -1, -1):
             l = self.g_down[i]
             skip_g = dcat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
@@ -366,7 +413,10 @@ class Pix2PixTrainer:
             else:
                 g = ops.instnorm_lrelu_bwd2(g, skip_g, ctx.raw[i], ctx.stats[i], LRELU)
             g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0))
-            self._mark(self.pG, grp); grp += 1
+            self._mark(self.pG, grp)
+            if update:
+                self._update_group(grp, l, hyper_dev)
+            grp += 1
 
     # ------------------------------------------------------------------------------------------------------------
     # discriminator
@@ -459,12 +509,13 @@ class Pix2PixTrainer:
         gd = self.d_backward(saved_g, dzg, want_w=False, need_input_grad=True)
         dh = ops.p2p_tanh_l1_bwd(gctx.h, tgt, gd, self.lambda_l1 / (B * C * H * W))
         engine.side_stream = self._side if self.overlap_wgrad else None
-        self.g_backward(gctx, dh)
+        in_bwd = update and self.opt_in_backward and not self.pG.bucketer.enabled
+        self.g_backward(gctx, dh, update=in_bwd, hyper_dev=hyper_dev)
         self._join()
-        if update:
+        if update and not in_bwd:
             self.pG.adam(self.lr, self.betas, self.eps, self.wd, hyper_dev)
             self.packG.repack()
-        else:
+        elif not update:
             self.pG.bucketer.wait_all()
         return losses, fake
 
@@ -535,3 +586,79 @@ class Pix2PixTrainer:
         zeros = torch.zeros_like(fake)
         ops.p2p_tanh_l1_fwd(ctx.h, src[:, :self.out_channels].contiguous(), zeros, d_in, fake)
         return fake
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the same passes without a trainer: what the autograd face of the two modules runs (pix2pix.py)
+# ----------------------------------------------------------------------------------------------------------------------
+class _NoExchange:
+    enabled = False
+
+    def start_step(self) -> None:
+        pass
+
+    def mark_ready_ordered(self, group_index, side) -> None:
+        pass
+
+
+class _GradSet:
+    def __init__(self):
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.bucketer = _NoExchange()
+
+
+class NetRunner:
+    """``g_forward`` / ``g_backward`` / ``d_forward`` / ``d_backward`` of ``Pix2PixTrainer`` on ONE module's own parameters
+    (no flat buffers, no optimiser, no side stream): ``Pix2PixGenerator.forward`` and ``PatchGANDiscriminator.forward`` are
+    each a single autograd node over these passes, so the module face launches the same HIP kernels as the fused trainer
+    -- LeakyReLU / ReLU in the conv epilogues, ReLU'd skips written into the concatenation buffers by the norm pass, no
+    torch activation, ``cat`` or ``pad``.  The packed MFMA operands are refreshed whenever a weight's version changes
+    (an optimiser step, ``load_state_dict``)."""
+    g_forward = Pix2PixTrainer.g_forward
+    g_backward = Pix2PixTrainer.g_backward
+    d_forward = Pix2PixTrainer.d_forward
+    d_backward = Pix2PixTrainer.d_backward
+    _mark = Pix2PixTrainer._mark
+
+    def __init__(self, net, precision: str = "bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.net = net
+        self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.is_generator = isinstance(net, Pix2PixGenerator)
+        self.pG, self.pD = _GradSet(), _GradSet()
+        self._key, self._packer = None, None
+        self.overlap_wgrad = False
+
+    def _layers(self) -> List[_Layer]:
+        return self.g_down + self.g_up if self.is_generator else self.d_layers
+
+    def refresh(self) -> None:
+        """(Re)build the layer list when the parameters moved, repack when a weight changed."""
+        net = self.net
+        ptrs = tuple(p.data_ptr() for p in net.parameters())
+        vers = tuple(p._version for p in net.parameters())
+        if self._key is None or self._key[0] != ptrs:
+            if next(net.parameters()).device.type != "cuda":
+                raise RuntimeError("stain2stain_amd: the pix2pix networks run on the GPU only (no CPU fallback)")
+            if self.is_generator:
+                self.n = len(net.downs)
+                self.g_down = [_Layer(f"downs.{i}", "s2", m.weight, m.bias) for i, m in enumerate(net.downs)]
+                self.g_up = [_Layer(f"ups.{j}", "t2", m.weight, m.bias) for j, m in enumerate(net.ups)]
+            else:
+                self.d_layers = [_Layer(name, kind, m.weight, m.bias) for name, kind, m in net.conv_layers()]
+            self._packer = _Packer(self._layers(), self.dtype)                # packs
+        elif self._key[1] != vers:
+            self._packer.repack()
+        self._key = (ptrs, vers)
+
+    def new_grads(self) -> Dict[str, torch.Tensor]:
+        """Fresh gradient tensors by parameter name (autograd keeps what ``backward`` returns): weights are written whole
+        by their kernels; biases start at zero -- the one in front of an InstanceNorm has an exactly zero gradient and no
+        kernel."""
+        out = {}
+        for l in self._layers():
+            out[l.name + ".weight"] = torch.empty_like(l.weight, memory_format=torch.contiguous_format)
+            if l.bias is not None:
+                out[l.name + ".bias"] = torch.zeros_like(l.bias)
+        return out

@@ -86,3 +86,31 @@ def test_pix2pix_graph_step_is_bit_equal_to_eager(prec):
     for i in range(len(data)):
         assert torch.equal(runs[True][1][i], runs[False][1][i]), f"generator differs after step {i}"
         assert torch.equal(runs[True][2][i], runs[False][2][i]), f"discriminator differs after step {i}"
+
+
+@pytest.mark.parametrize("prec,side", [("bf16", True), ("fp32", True), ("bf16", False)])
+def test_pix2pix_update_in_backward_is_bit_equal_to_the_end_of_step_update(prec, side):
+    """The generator's Adam slices + repacks issued layer by layer inside the backward pass (on the side stream behind
+    each weight gradient; ``Pix2PixTrainer.opt_in_backward``) against one Adam launch + one repack after the join:
+    losses, parameters, both Adam moments and the packed MFMA operands after every step."""
+    from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator, Pix2PixTrainer
+    data = _batches(4, 2, 64, 8)
+    runs = {}
+    for in_bwd in (False, True):
+        torch.manual_seed(1984)
+        G, D = Pix2PixGenerator(ngf=16, num_downs=5).to(DEV), PatchGANDiscriminator(ndf=16).to(DEV)
+        tr = Pix2PixTrainer(G, D, precision=prec)
+        tr.opt_in_backward, tr.overlap_wgrad = in_bwd, side
+        rec = []
+        for src, tgt, _ in data:
+            ls = tr.step(src, tgt).clone()
+            rec.append((ls, tr.pG.p.clone(), tr.pG.m.clone(), tr.pG.v.clone(), tr.pD.p.clone(),
+                        [l.wf.clone() for l in tr.g_down + tr.g_up], [l.wd.clone() for l in tr.g_down + tr.g_up]))
+        torch.cuda.synchronize()
+        assert tr.pG.step_count == len(data)
+        runs[in_bwd] = rec
+    for i, (a, b) in enumerate(zip(runs[True], runs[False])):
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y), f"step {i}"
+        for x, y in zip(a[5] + a[6], b[5] + b[6]):
+            assert torch.equal(x, y), f"packed operand differs after step {i}"

@@ -1,7 +1,7 @@
 """The fused pix2pix G + D step (stain2stain_amd.pix2pix_engine) and its kernels.
 
 Oracle: ``oracle/pix2pix_oracle.py`` -- the same two networks on torch's own layers, fp32 on the CPU, stepped with
-``stain2stain_amd.pix2pix.pix2pix_losses`` / ``pix2pix_step`` (plain torch code when handed torch modules) and
+``oracle.pix2pix_oracle.pix2pix_losses`` / ``pix2pix_step`` (plain torch code when handed torch modules) and
 ``torch.optim.Adam``.  PARITY UNPINNED with respect to the reference repository, which has no pix2pix model
 (SURVEY.md F1); what is pinned here is agreement with torch's operators.
 
@@ -215,7 +215,7 @@ def _build(ngf, ndf, num_downs, seed, bf16_weights, n_layers=3):
 
 def _oracle_eval(Go, Do, src, tgt, dtype=torch.float32):
     """fake, loss_D, loss_G and all gradients of the oracle at its current parameters (pix2pix_losses is plain torch)."""
-    from stain2stain_amd.pix2pix import pix2pix_losses
+    from oracle.pix2pix_oracle import pix2pix_losses
     Go, Do = Go.to(dtype), Do.to(dtype)
     fake, ld, lg = pix2pix_losses(Go, Do, src.to(dtype), tgt.to(dtype))
     # what the G + D step uses: the discriminator is updated on loss_D alone (the generator's pass through it leaves its
@@ -288,7 +288,7 @@ def test_baseline_config0_literal_form_2_level_unet_1_layer_patchgan():
     (the reference has no such model, SURVEY F1: the oracle is the torch-layer restatement).  Output, losses, every
     gradient at 1e-3, and two G + D Adam steps against torch.optim.Adam on the oracle."""
     from stain2stain_amd import Pix2PixTrainer
-    from stain2stain_amd.pix2pix import pix2pix_step
+    from oracle.pix2pix_oracle import pix2pix_step
     G, D, Go, Do = _build(16, 16, 2, 1984, bf16_weights=False, n_layers=1)
     assert len(G.downs) == 2 and [k for _, k, _ in D.conv_layers()] == ["s2", "s1", "s1"]
     # a generator this shallow has no InstanceNorm at all and 16k ReLU / LeakyReLU decisions on raw conv outputs: the
@@ -345,7 +345,7 @@ def test_training_steps_follow_the_oracle_adam_loop():
     both networks) against pix2pix_step over the oracle networks with torch.optim.Adam: losses step by step and the
     parameters afterwards."""
     from stain2stain_amd import Pix2PixTrainer
-    from stain2stain_amd.pix2pix import pix2pix_step
+    from oracle.pix2pix_oracle import pix2pix_step
     G, D, Go, Do = _build(16, 16, 5, 7, bf16_weights=False)
     g = torch.Generator().manual_seed(70)
     batches = [(torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1)

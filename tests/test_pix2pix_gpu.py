@@ -31,7 +31,7 @@ def _pair(seed=1984):
 
 
 def test_networks_match_the_torch_layer_oracle():
-    from stain2stain_amd.pix2pix import pix2pix_losses
+    from oracle.pix2pix_oracle import pix2pix_losses
     G, D, Go, Do = _pair()
     g = torch.Generator().manual_seed(7)
     src = (torch.rand(4, 3, 64, 64, generator=g) * 2 - 1).to(torch.bfloat16).float()
@@ -62,7 +62,7 @@ def test_networks_match_the_torch_layer_oracle():
 
 def test_g_plus_d_step_trains():
     """A few G + D steps on a fixed batch: finite losses, the L1-dominated generator loss goes down."""
-    from stain2stain_amd.pix2pix import pix2pix_step
+    from oracle.pix2pix_oracle import pix2pix_step
     G, D, _, _ = _pair(3)
     og = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     od = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
@@ -103,3 +103,40 @@ def test_headline_networks_forward_against_the_oracle():
     assert fake.shape == (2, 3, 256, 256) and logits.shape == (2, 1, 30, 30)
     print(f"headline G output rel-L2 {_l2(fake, fake_o):.3e}, D logits rel-L2 {_l2(logits, logits_o):.3e}")
     assert _l2(fake, fake_o) < 3e-2 and _l2(logits, logits_o) < 3e-2      # measured 7.0e-3 / 6.0e-3
+
+
+def test_module_face_fp32_mode_matches_the_oracle_and_runs_on_the_engine_passes():
+    """``G(x)`` / ``D(a, b)`` under autograd are one node each over the fused engine's passes (pix2pix_engine.NetRunner):
+    in the fp32 parity mode the outputs, both losses and every gradient follow the torch-layer oracle at 1e-3 (gradients
+    relative to the largest gradient norm of the network); an optimiser step re-packs the MFMA operands."""
+    from oracle import pix2pix_oracle as O
+    from stain2stain_amd.pix2pix import PatchGANDiscriminator, Pix2PixGenerator, _DiscriminatorFn, _GeneratorFn
+    torch.manual_seed(5)
+    G, D = Pix2PixGenerator(ngf=16, num_downs=5, precision="fp32"), PatchGANDiscriminator(ndf=16, precision="fp32")
+    Go, Do = O.OracleGenerator(ngf=16, num_downs=5), O.OracleDiscriminator(ndf=16)
+    Go.load_state_dict(G.state_dict()); Do.load_state_dict(D.state_dict())
+    G, D = G.to(DEV), D.to(DEV)
+    g = torch.Generator().manual_seed(17)
+    src, tgt = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    fake, ld, lg = O.pix2pix_losses(G, D, src.to(DEV), tgt.to(DEV))
+    fake_o, ld_o, lg_o = O.pix2pix_losses(Go, Do, src, tgt)
+    assert type(fake.grad_fn).__name__ == _GeneratorFn.__name__ + "Backward"
+    assert type(D(src.to(DEV), tgt.to(DEV)).grad_fn).__name__ == _DiscriminatorFn.__name__ + "Backward"
+    assert float((fake.detach().cpu() - fake_o).abs().max()) < 1e-3 * float(fake_o.abs().max())
+    assert abs(float(ld) - float(ld_o)) < 1e-3 * abs(float(ld_o)) and abs(float(lg) - float(lg_o)) < 1e-3 * abs(float(lg_o))
+    (ld + lg).backward()
+    (ld_o + lg_o).backward()
+    for mod, ref in ((G, Go), (D, Do)):
+        scale = max(float(q.grad.norm()) for q in ref.parameters())
+        for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+            err = float((p.grad.cpu() - q.grad).norm())
+            assert err < 3e-3 * scale, (k, err / scale)
+    # a parameter update is seen by the next forward (packed operands are refreshed on a version change)
+    before = G(src.to(DEV)).detach().clone()
+    with torch.no_grad():
+        for p in G.parameters():
+            p.mul_(1.01)
+    after = G(src.to(DEV)).detach()
+    assert not torch.equal(before, after)
+    with pytest.raises(RuntimeError, match="no gradient with respect to the input"):
+        G(src.to(DEV).requires_grad_(True)).sum().backward()
