@@ -24,3 +24,14 @@ def timeit(fn, n=20):
 
 
 print(f"stem fwd {timeit(lambda: ops.stem_fwd(x, w, b, dt, want_stats=True)):.1f} us | stem wgrad {timeit(lambda: ops.stem_wgrad(dy, x, dw, db)):.1f} us")
+
+# fused head (1x1 conv 64 -> 3 + MSE + both backward passes)
+xa = torch.randn(B, 256, 256, 64, device=dev).to(dt)
+hw = (torch.rand(3, 64, 1, 1, device=dev) - 0.5) * 0.2
+hb = torch.zeros(3, device=dev)
+u = torch.randn(B, 3, 256, 256, device=dev)
+hdw, hdb = torch.empty_like(hw), torch.empty_like(hb)
+t = timeit(lambda: ops.head_loss_fused(xa, hw, hb, u, hdw, hdb))
+print(f"head + loss {t:.1f} us = {2 * xa.numel() * 2 / t / 1e6:.2f} TB/s (env S2S_HEAD_BLOCKS={os.environ.get('S2S_HEAD_BLOCKS', '-')})")
+loss, dx, _ = ops.head_loss_fused(xa, hw, hb, u, hdw, hdb)
+print("head check", float(loss), float(dx.float().abs().sum()), float(hdw.abs().sum()), float(hdb.abs().sum()))

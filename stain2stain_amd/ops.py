@@ -722,10 +722,16 @@ class capture_graph:
     destroy an earlier, unreachable ``torch.cuda.CUDAGraph`` (e.g. the sampler's GraphedVelocity, which forms a cycle with
     its network): hipGraphExecDestroy / the release of its private memory pool inside another stream capture aborts the
     process (seen on ROCm 7 / torch 2.10, whose ``torch.cuda.graph`` no longer collects on entry).  So: collect first,
-    keep the collector off while capturing, restore it afterwards."""
+    keep the collector off while capturing, restore it afterwards.
+
+    Capture mode ``thread_local``: with a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events of
+    earlier (eager) collectives with hipEventQuery; under the default ``global`` mode any such call from another thread
+    while this thread captures is an error, which the watchdog turns into an abort of the process (seen in the full GPU
+    suite: ``bench.py`` under S2S_FORCE_DDP=1 died in WorkNCCL::finishedGPUExecutionInternal when the graph leg's capture
+    raced the watchdog's poll of the warm-up steps' all-reduces)."""
 
     def __init__(self, graph: "torch.cuda.CUDAGraph"):
-        self._ctx = torch.cuda.graph(graph)
+        self._ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")
 
     def __enter__(self):
         import gc
