@@ -35,7 +35,7 @@ for (H, c0, c1, cout) in FWD:
     w = (torch.rand(cout, cin, 3, 3, device=dev) - 0.5) * 0.1 * float(os.environ.get("ZERO", "1") != "0")
     wf, wd = ops.pack_conv3x3(w, dt)
     dy = (torch.rand(B, H, H, cout, device=dev) * 2 - 1).to(dt)
-    bias = torch.zeros(cout, device=dev)
+    bias = None if os.environ.get("NOBIAS") else torch.zeros(cout, device=dev)      # (the training path convolves without it)
     gflop = 2.0 * B * H * H * cout * 9 * cin / 1e9
     x0 = x[..., :c0]; x1 = x[..., c0:] if c1 else None
     y = torch.empty(B, H, H, cout, device=dev, dtype=dt)
