@@ -344,6 +344,17 @@ int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const float* gamm
 int s2s_instnorm_lrelu_bwd2(int dtype, const void* g, int ldg, const void* g2, int ldg2, const void* x, int ldx,
                             const float* stats, void* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
                             float* work, int B, int H, int W, int C, float slope, void* stream);
+/* The single-launch forms (bf16, no affine, maps of at most 32 x 32: s2s_instnorm_split_ok() != 0) with the input folded
+ * from a split-K convolution's partial slabs, float[S][B*H*W][C] as s2s_conv4x4s2_nhwc / s2s_convt4x4s2_nhwc leave them in
+ * kwork when called with y == NULL -- one launch instead of reduce + norm, bit-identical to the two-launch form.
+ * fwd: raw (bf16, what the backward reads) <- fold + bias, then s2s_instnorm_lrelu_fwd2 on it; bwd: g <- fold. */
+int s2s_instnorm_split_ok(int dtype, int H, int W, int C);
+int s2s_instnorm_lrelu_fwd_split(int dtype, const float* slabs, int S, const float* bias, void* raw, int ldraw, void* y,
+                                 int ldy, void* y2, int ldy2, float* stats, int B, int H, int W, int C, float eps,
+                                 float slope, void* stream);
+int s2s_instnorm_lrelu_bwd_split(int dtype, const float* gslabs, int S, const void* g2, int ldg2, const void* x, int ldx,
+                                 const float* stats, void* dx, int lddx, int B, int H, int W, int C, float slope,
+                                 void* stream);
 /* s2s_pack_conv4x4 with the operands in the activation dtype; the batched form re-packs every 4x4 layer of a network in
  * one launch after the fused Adam step: desc = device long[nlayers][7] {w master, wf, wd, Cout, Cin, stride == 2, first
  * block}, a layer occupies s2s_pack_conv4x4_blocks() blocks, total = their sum. */

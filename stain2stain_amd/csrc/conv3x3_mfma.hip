@@ -2498,6 +2498,10 @@ extern "C" int s2s_conv4x4s2_ksplit(int B, int H, int W, int Cout, int Cin) {
 extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wf, const float* bias, void* y,
                                   int ldy, void* y2, int ldy2, int act, float act_slope, float* kwork, int B, int H, int W,
                                   int Cout, void* stream) {
+  // y == NULL: leave the split's partial slabs in kwork for a consumer that folds them (s2s_instnorm_lrelu_fwd_split /
+  // _bwd_split); only where the launch IS split -- S2S_ERR_NULL otherwise
+  const bool defer = !y;
+  if (defer) { if (!kwork || s2s_conv4x4s2_ksplit(B, H, W, Cout, Cin) < 2 || act || y2) return S2S_ERR_NULL; y = kwork; ldy = Cout; }
   if (!x || !wf || !y) return S2S_ERR_NULL;
   if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin < 8 || (Cin & (Cin - 1)) || (ldx % 8) || ldx < Cin || (Cout % 8) || (ldy % 8) || ldy < Cout) return S2S_ERR_SHAPE;
@@ -2527,7 +2531,7 @@ extern "C" int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, co
     case 4: rc = launch_convkxk<8, 16, 128, 2, 2, 2, 0, 1>(a, s); break;
     default: rc = launch_convkxk<8, 16, 64, 2, 2, 2, 0, 1>(a, s);
   }
-  if (rc != S2S_OK || !a.kpart) return rc;
+  if (rc != S2S_OK || !a.kpart || defer) return rc;
   const long npix = (long)B * H * W, pieces = npix * (Cout / 8);
   long nb = (pieces + 255) / 256;
   if (nb > 4096) nb = 4096;
@@ -2546,6 +2550,8 @@ extern "C" int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin) {
 
 extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wd, const float* bias, void* y,
                                    int ldy, float* kwork, int B, int h, int w, int C, void* stream) {
+  const bool defer = !y;                                // as in s2s_conv4x4s2_nhwc
+  if (defer) { if (!kwork || s2s_convt4x4s2_ksplit(B, h, w, C, Cin) < 2) return S2S_ERR_NULL; y = kwork; ldy = C; }
   if (!x || !wd || !y) return S2S_ERR_NULL;
   if (dtype != S2S_BF16) return S2S_ERR_DTYPE;
   if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C % 64) || Cin <= 0 || (Cin % 8) || (ldx % 8) || ldx < Cin || (ldy % 8) || ldy < C) return S2S_ERR_SHAPE;
@@ -2574,7 +2580,7 @@ extern "C" int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, c
     case 4: rc = launch_convkxk<8, 16, 128, 2, 2, 2, 1, 2>(a, s); break;
     default: rc = launch_convkxk<8, 16, 64, 2, 2, 2, 1, 2>(a, s);
   }
-  if (rc != S2S_OK || !a.kpart) return rc;
+  if (rc != S2S_OK || !a.kpart || defer) return rc;
   const long npix = (long)B * 4 * h * w, pieces = npix * (C / 8);
   long nb = (pieces + 255) / 256;
   if (nb > 4096) nb = 4096;

@@ -355,12 +355,39 @@ __device__ __forceinline__ f32x8 cvt8(const bf16x8& a) {
   return r;
 }
 
-template <bool BWD, bool G2>
+// SPLIT: the tensor a split-K convolution would have produced is folded here from its fp32 partial slabs
+// slabs[S][B*HW][C] (+ bias) instead of by a reduce launch of its own -- the forward's input x (the folded, bf16-rounded
+// tensor is also written to xw: the backward reads it), the backward's incoming gradient g.  Same order of additions and
+// the same rounding as convk_splitk_reduce_kernel, so the results are those of the two-launch form bit for bit.
+struct InSplit {
+  const float* slabs;
+  const float* bias;
+  long stride;            // elements between slabs
+  int S;
+  bf16_t* xw;             // forward: where the folded tensor goes (pixel stride ldx)
+};
+
+__device__ __forceinline__ bf16x8 in_fold_piece(const InSplit& sp, long elem, int c8) {
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = sp.bias ? sp.bias[c8 + k] : 0.f;
+  for (int z = 0; z < sp.S; ++z) {
+    const f32x8 v = load8(sp.slabs + (long)z * sp.stride + elem);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v.v[k];
+  }
+  bf16x8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = (bf16_t)acc[k];
+  return r;
+}
+
+template <bool BWD, bool G2, bool SPLIT = false>
 __global__ __launch_bounds__(512) void in_small_res_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ g,
                                                            int ldg, const bf16_t* __restrict__ g2, int ldg2,
                                                            bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ y2, int ldy2,
                                                            float* __restrict__ stats, int B, int HW, int C, float eps,
-                                                           float slope) {
+                                                           float slope, InSplit sp = InSplit{}) {
   const int pc = threadIdx.x & 7, wl = threadIdx.x >> 3, wave = threadIdx.x >> 6;
   const int n = blockIdx.y, c8 = blockIdx.x * IN_RCG + pc * 8;
   const bool live = c8 < C;
@@ -377,15 +404,24 @@ __global__ __launch_bounds__(512) void in_small_res_kernel(const bf16_t* __restr
     for (int it = 0; it < IN_RIT; ++it) {
       const int p = wl + it * 64;
       if (p < HW) {
-        xr[it] = *reinterpret_cast<const bf16x8*>(xb + (long)p * ldx);
-        if (BWD) gr[it] = *reinterpret_cast<const bf16x8*>(g + ((long)n * HW + p) * ldg + c8);
+        if (SPLIT && !BWD) {
+          xr[it] = in_fold_piece(sp, ((long)n * HW + p) * C + c8, c8);
+          *reinterpret_cast<bf16x8*>(sp.xw + ((long)n * HW + p) * ldx + c8) = xr[it];
+        } else {
+          xr[it] = *reinterpret_cast<const bf16x8*>(xb + (long)p * ldx);
+        }
+        if (BWD) {
+          if (SPLIT) gr[it] = in_fold_piece(sp, ((long)n * HW + p) * C + c8, c8);
+          else gr[it] = *reinterpret_cast<const bf16x8*>(g + ((long)n * HW + p) * ldg + c8);
+        }
       }
     }
     if (BWD) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { mu[k] = stats[o + k]; is[k] = stats[BC + o + k]; sc[k] = stats[2 * BC + o + k]; sh[k] = stats[3 * BC + o + k]; }
     } else {
-      const f32x8 v0 = load8(xb);                       // the shift of in_small_kernel: the channel's first pixel
+      // the shift of in_small_kernel: the channel's first pixel
+      const f32x8 v0 = SPLIT ? cvt8(in_fold_piece(sp, (long)n * HW * C + c8, c8)) : load8(xb);
 #pragma unroll
       for (int k = 0; k < 8; ++k) shift0[k] = v0.v[k];
     }
@@ -556,6 +592,53 @@ extern "C" int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const 
   else if (dtype == S2S_F32) { S2S_IN_FWD(float); }
   else return S2S_ERR_DTYPE;
 #undef S2S_IN_FWD
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// The single-launch forms with the input folded from a split-K convolution's partial slabs (bf16, no affine, maps of at
+// most 32 x 32: s2s_instnorm_split_ok).  slabs: float[S][B*H*W][C] as s2s_conv4x4s2_nhwc / s2s_convt4x4s2_nhwc leave them
+// with y == NULL; bias: the convolution's (or NULL).
+extern "C" int s2s_instnorm_split_ok(int dtype, int H, int W, int C) {
+  return dtype == S2S_BF16 && H > 0 && W > 0 && (long)H * W <= IN_SMALL_HW && (long)H * W > 1 && C > 0 && (C % 8) == 0;
+}
+
+// forward: raw (bf16, pixel stride ldraw) <- fold(slabs) + bias; then as s2s_instnorm_lrelu_fwd2 on raw
+extern "C" int s2s_instnorm_lrelu_fwd_split(int dtype, const float* slabs, int S, const float* bias, void* raw, int ldraw,
+                                            void* y, int ldy, void* y2, int ldy2, float* stats, int B, int H, int W, int C,
+                                            float eps, float slope, void* stream) {
+  if (!slabs || !raw || !y || !stats) return S2S_ERR_NULL;
+  if (!s2s_instnorm_split_ok(dtype, H, W, C) || S < 1 || !in_args_ok(B, H, W, C, ldraw, ldy) || (y2 && (ldy2 % 8)))
+    return S2S_ERR_SHAPE;
+  if (((uintptr_t)slabs & 15) || ((uintptr_t)raw & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return S2S_ERR_ALIGN;
+  const int HW = H * W;
+  InSplit sp{slabs, bias, (long)B * HW * C, S, (bf16_t*)raw};
+  hipLaunchKernelGGL((in_small_res_kernel<false, false, true>), dim3(cdiv(C, IN_RCG), B), dim3(512), 0, (hipStream_t)stream,
+                     (const bf16_t*)raw, ldraw, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, (bf16_t*)y, ldy,
+                     (bf16_t*)y2, ldy2, stats, B, HW, C, eps, slope, sp);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// backward: g <- fold(gslabs) (bf16-rounded, no bias); then as s2s_instnorm_lrelu_bwd2
+extern "C" int s2s_instnorm_lrelu_bwd_split(int dtype, const float* gslabs, int S, const void* g2, int ldg2, const void* x,
+                                            int ldx, const float* stats, void* dx, int lddx, int B, int H, int W, int C,
+                                            float slope, void* stream) {
+  if (!gslabs || !x || !stats || !dx) return S2S_ERR_NULL;
+  if (!s2s_instnorm_split_ok(dtype, H, W, C) || S < 1 || !in_args_ok(B, H, W, C, ldx, lddx) || (g2 && (ldg2 % 8)))
+    return S2S_ERR_SHAPE;
+  if (((uintptr_t)gslabs & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)g2 & 15)) return S2S_ERR_ALIGN;
+  const int HW = H * W;
+  InSplit sp{gslabs, nullptr, (long)B * HW * C, S, nullptr};
+  const dim3 rg(cdiv(C, IN_RCG), B);
+  if (g2)
+    hipLaunchKernelGGL((in_small_res_kernel<true, true, true>), rg, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)nullptr, 0, (const bf16_t*)g2, ldg2, (bf16_t*)dx, lddx, (bf16_t*)nullptr, 0,
+                       const_cast<float*>(stats), B, HW, C, 0.f, slope, sp);
+  else
+    hipLaunchKernelGGL((in_small_res_kernel<true, false, true>), rg, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, (bf16_t*)dx, lddx, (bf16_t*)nullptr, 0,
+                       const_cast<float*>(stats), B, HW, C, 0.f, slope, sp);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

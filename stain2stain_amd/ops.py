@@ -1061,6 +1061,33 @@ def convkxk_wgrad(dy: torch.Tensor, x: torch.Tensor, grad: torch.Tensor, ks: int
     _native.check(rc, "convkxk_wgrad")
 
 
+class SplitSum:
+    """The partial slabs of a split-K stride-2 convolution whose reduce launch was left out (``defer=True``): the consumer
+    -- the single-launch InstanceNorm of the inner U-Net levels -- folds them itself.  ``slabs``: fp32 [S, B*H*W, C]."""
+
+    def __init__(self, slabs: torch.Tensor, bias: Optional[torch.Tensor], shape, dtype: torch.dtype):
+        self.slabs, self.bias, self.shape, self.dtype = slabs, bias, tuple(shape), dtype
+
+
+def instnorm_split_ok(dtype: torch.dtype, H: int, W: int, C: int) -> bool:
+    return dtype == torch.bfloat16 and bool(_L().s2s_instnorm_split_ok(BF16, int(H), int(W), int(C)))
+
+
+def instnorm_lrelu_fwd2_split(sp: SplitSum, slope: float, out: torch.Tensor, out2: Optional[torch.Tensor] = None,
+                              eps: float = 1e-5):
+    """instnorm_lrelu_fwd2 on the tensor ``sp`` stands for; returns (stats, raw): raw = that tensor, as the backward needs
+    it.  One launch instead of reduce + norm, the same bits."""
+    B, H, W, C = sp.shape
+    raw = torch.empty((B, H, W, C), dtype=sp.dtype, device=sp.slabs.device)
+    py, ldy = _nhwc(out)
+    p2, ld2 = (0, 8) if out2 is None else _nhwc(out2)
+    stats = torch.empty((4, B, C), dtype=torch.float32, device=raw.device)
+    rc = _L().s2s_instnorm_lrelu_fwd_split(_dt(raw), _f32(sp.slabs), sp.slabs.shape[0], _f32(sp.bias), raw.data_ptr(), C,
+                                           py, ldy, p2, ld2, _f32(stats), B, H, W, C, eps, slope, _stream())
+    _native.check(rc, "instnorm_lrelu_fwd_split")
+    return stats, raw
+
+
 @_timed("instnorm_lrelu_fwd")
 def instnorm_lrelu_fwd2(x: torch.Tensor, slope: float, out: torch.Tensor, out2: Optional[torch.Tensor] = None,
                         eps: float = 1e-5):
@@ -1082,12 +1109,20 @@ def instnorm_lrelu_fwd2(x: torch.Tensor, slope: float, out: torch.Tensor, out2: 
 @_timed("instnorm_lrelu_bwd")
 def instnorm_lrelu_bwd2(g: torch.Tensor, g2: Optional[torch.Tensor], x: torch.Tensor, stats: torch.Tensor,
                         slope: float) -> torch.Tensor:
-    """dx of InstanceNorm + LeakyReLU for the gradients g (wrt the LeakyReLU output) and g2 (wrt the relu copy)."""
+    """dx of InstanceNorm + LeakyReLU for the gradients g (wrt the LeakyReLU output; a tensor or the ``SplitSum`` of the
+    data gradient that produced it) and g2 (wrt the relu copy)."""
     B, H, W, C = x.shape
-    pg, ldg = _nhwc(g)
     p2, ld2 = (0, 8) if g2 is None else _nhwc(g2)
     px, ldx = _nhwc(x)
     dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    if isinstance(g, SplitSum):
+        if g.shape != (B, H, W, C):
+            raise RuntimeError("stain2stain_amd: split gradient does not match the activation")
+        rc = _L().s2s_instnorm_lrelu_bwd_split(_dt(x), _f32(g.slabs), g.slabs.shape[0], p2, ld2, px, ldx, _f32(stats),
+                                               dx.data_ptr(), C, B, H, W, C, slope, _stream())
+        _native.check(rc, "instnorm_lrelu_bwd_split")
+        return dx
+    pg, ldg = _nhwc(g)
     nb = _L().s2s_instnorm_blocks(B, H, W, C)
     _native.check(min(nb, 0), "instnorm_blocks")
     work = torch.empty(2 * B * C * nb + 2 * B * C, dtype=torch.float32, device=x.device)
@@ -1244,8 +1279,10 @@ def fused_s2_ok(dtype: torch.dtype, c: int) -> bool:
 @_timed("convkxk_mfma", lambda x, w_packed, bias, cout, **kw: 2.0 * x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) * cout
         * 16 * x.shape[3])
 def conv4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, *, act: bool = False,
-              slope: float = 0.0, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Conv2d(k=4, s=2, p=1) from the plain NHWC bf16 input [B,2H,2W,Cin] (no space-to-depth pass)."""
+              slope: float = 0.0, out2: Optional[torch.Tensor] = None, defer: bool = False):
+    """nn.Conv2d(k=4, s=2, p=1) from the plain NHWC bf16 input [B,2H,2W,Cin] (no space-to-depth pass).  ``defer``: where the
+    launch is split-K and the output is a map the single-launch InstanceNorm takes, return the ``SplitSum`` of its partial
+    slabs instead of launching the reduce."""
     B, Hi, Wi, cin = x.shape
     H, W = Hi // 2, Wi // 2
     if Hi % 2 or Wi % 2 or not fused_s2_ok(x.dtype, cin) or w_packed.dtype != x.dtype:
@@ -1260,16 +1297,17 @@ def conv4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     nsplit = _L().s2s_conv4x4s2_ksplit(B, H, W, cout, cin)
     _native.check(min(nsplit, 0), "conv4x4s2_ksplit")
     kwork = torch.empty((nsplit, B * H * W, cout), dtype=torch.float32, device=x.device) if nsplit > 1 else None
-    rc = _L().s2s_conv4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), y.data_ptr(), cout, p2, ld2, int(act),
-                                 float(slope), _f32(kwork), B, H, W, cout, _stream())
+    defer = defer and nsplit > 1 and not act and out2 is None and instnorm_split_ok(x.dtype, H, W, cout)
+    rc = _L().s2s_conv4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), 0 if defer else y.data_ptr(), cout, p2,
+                                 ld2, int(act), float(slope), _f32(kwork), B, H, W, cout, _stream())
     _native.check(rc, "conv4x4s2")
-    return y
+    return SplitSum(kwork, bias, (B, H, W, cout), x.dtype) if defer else y
 
 
 @_timed("convkxk_mfma", lambda x, w_packed, bias, cout, **kw: 2.0 * x.shape[0] * 4 * x.shape[1] * x.shape[2] * cout * 4
         * x.shape[3])
 def convT4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, *,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, defer: bool = False):
     """nn.ConvTranspose2d(k=4, s=2, p=1) (= the stride-2 convolution's data gradient) by sub-pixel phase: NHWC bf16
     [B,h,w,Cin] -> plain [B,2h,2w,cout], cout % 64 == 0; w_packed = the data-gradient operand."""
     B, h, w, cin = x.shape
@@ -1285,7 +1323,8 @@ def convT4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     nsplit = _L().s2s_convt4x4s2_ksplit(B, h, w, cout, cin)
     _native.check(min(nsplit, 0), "convT4x4s2_ksplit")
     kwork = torch.empty((nsplit, B * 4 * h * w, cout), dtype=torch.float32, device=x.device) if nsplit > 1 else None
-    rc = _L().s2s_convt4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), py, ldy, _f32(kwork), B, h, w, cout,
-                                  _stream())
+    defer = defer and nsplit > 1 and out is None and instnorm_split_ok(x.dtype, 2 * h, 2 * w, cout)      # (see conv4x4s2)
+    rc = _L().s2s_convt4x4s2_nhwc(_dt(x), px, ldx, cin, _ptr(w_packed), _f32(bias), 0 if defer else py, ldy, _f32(kwork), B,
+                                  h, w, cout, _stream())
     _native.check(rc, "convT4x4s2")
-    return y
+    return SplitSum(kwork, bias, (B, 2 * h, 2 * w, cout), x.dtype) if defer else y

@@ -35,6 +35,9 @@ from .ddp import ALIGN, GradBucketer, all_reduce_mean_scalar, broadcast_from_ran
 from .pix2pix import PatchGANDiscriminator, Pix2PixGenerator
 
 LRELU = 0.2
+# The inner U-Net levels' split-K convolutions leave their reduce to the single-launch InstanceNorm that consumes them
+# (ops.SplitSum; 11 launches fewer per step, the same bits).  S2S_P2P_FOLD_IN_NORM=0: separate reduce launches.
+FOLD_IN_NORM = os.environ.get("S2S_P2P_FOLD_IN_NORM", "1") != "0"
 
 
 class FlatParams:
@@ -182,32 +185,33 @@ class _Packer:
 # ----------------------------------------------------------------------------------------------------------------------
 # layer forward / backward on the kernels
 # ----------------------------------------------------------------------------------------------------------------------
-def _conv_s2_fwd(l: _Layer, x: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None):
+def _conv_s2_fwd(l: _Layer, x: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None, defer: bool = False):
     """nn.Conv2d(k=4, s=2, p=1) of the plain NHWC tensor x.  Returns (y, saved): ``saved`` is what the weight gradient
     reads -- x itself on the layout-free bf16 kernels (the loader does the space-to-depth in its addresses), else the
     explicit space-to-depth image (fp32 parity mode)."""
     bias = None if l.bias is None else l.bias.detach()
-    if ops.fused_s2_ok(x.dtype, x.shape[3]):
-        return ops.conv4x4s2(x, l.wf, bias, l.conv_out, act=act, slope=slope, out2=out2), x
+    if ops.fused_s2_ok(x.dtype, x.shape[3]):      # (defer: a split launch leaves its reduce to the norm that follows)
+        return ops.conv4x4s2(x, l.wf, bias, l.conv_out, act=act, slope=slope, out2=out2, defer=defer), x
     xs = ops.space_to_depth_pad1_t(x)
     return ops.convkxk(xs, l.wf, bias, l.conv_out, 2, 0, act=act, slope=slope, out2=out2), xs
 
 
-def _conv_s2_bwd(l: _Layer, g: torch.Tensor, saved: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True):
+def _conv_s2_bwd(l: _Layer, g: torch.Tensor, saved: torch.Tensor, gw: torch.Tensor, need_dx: bool, want_w: bool = True,
+                 defer: bool = False):
     if want_w:      # (a leaf of the backward chain: on the side stream when the trainer has one, engine.run_on_side)
         engine.run_on_side(lambda: ops.convkxk_wgrad(g, saved, gw, 2, x_plain=(saved.shape[3] == l.conv_in)), (g,))
     if not need_dx:
         return None
     if g.dtype == torch.bfloat16 and l.conv_in % 64 == 0:
-        return ops.convT4x4s2(g, l.wd, None, l.conv_in)                  # data gradient by sub-pixel phase, plain output
+        return ops.convT4x4s2(g, l.wd, None, l.conv_in, defer=defer)     # data gradient by sub-pixel phase, plain output
     return ops.depth_to_space_unpad1_t(ops.convkxk(g, l.wd, None, 4 * l.conv_in, 2, 1))
 
 
-def _conv_t2_fwd(l: _Layer, x: torch.Tensor) -> torch.Tensor:
+def _conv_t2_fwd(l: _Layer, x: torch.Tensor, defer: bool = False):
     """nn.ConvTranspose2d(k=4, s=2, p=1): [B,h,w,Cin] -> [B,2h,2w,Cout]."""
     bias = None if l.bias is None else l.bias.detach()
     if x.dtype == torch.bfloat16 and l.conv_out % 64 == 0:
-        return ops.convT4x4s2(x, l.wd, bias, l.conv_out)
+        return ops.convT4x4s2(x, l.wd, bias, l.conv_out, defer=defer)
     # space-to-depth form: the four sub-pixel channel groups of the output share the layer's bias (bias_mod)
     return ops.depth_to_space_unpad1_t(ops.convkxk(x, l.wd, bias, 4 * l.conv_out, 2, 1, bias_mod=l.conv_out))
 
@@ -344,19 +348,28 @@ class Pix2PixTrainer:
                 a, saved = _conv_s2_fwd(l, x, act=True, slope=0.0)
                 ctx.raw.append(None); ctx.stats.append(None)
             else:
-                raw, saved = _conv_s2_fwd(l, x)
-                a = torch.empty_like(raw)
-                ctx.stats.append(ops.instnorm_lrelu_fwd2(raw, LRELU, a, skip))
+                raw, saved = _conv_s2_fwd(l, x, defer=FOLD_IN_NORM)
+                if isinstance(raw, ops.SplitSum):        # inner level: the norm folds the split-K slabs itself
+                    a = torch.empty(raw.shape, dtype=dt, device=dev)
+                    st, raw = ops.instnorm_lrelu_fwd2_split(raw, LRELU, a, skip)
+                else:
+                    a = torch.empty_like(raw)
+                    st = ops.instnorm_lrelu_fwd2(raw, LRELU, a, skip)
+                ctx.stats.append(st)
                 ctx.raw.append(raw)
             ctx.xs.append(saved)
             ctx.act.append(a)
             x = a
         for j, l in enumerate(self.g_up):
             xin = x if j == 0 else ctx.cat[j]
-            hraw = _conv_t2_fwd(l, xin)
+            hraw = _conv_t2_fwd(l, xin, defer=FOLD_IN_NORM and j < n - 1)
             if j < n - 1:
                 C = l.conv_out
-                ctx.ustats.append(ops.instnorm_lrelu_fwd2(hraw, 0.0, ctx.cat[j + 1][..., C:]))
+                if isinstance(hraw, ops.SplitSum):
+                    st, hraw = ops.instnorm_lrelu_fwd2_split(hraw, 0.0, ctx.cat[j + 1][..., C:])
+                else:
+                    st = ops.instnorm_lrelu_fwd2(hraw, 0.0, ctx.cat[j + 1][..., C:])
+                ctx.ustats.append(st)
                 ctx.uraw.append(hraw)
             else:
                 ctx.h = hraw
@@ -412,7 +425,8 @@ class Pix2PixTrainer:
                 g = ops.p2p_act_bwd(g, skip_g, ctx.act[0], LRELU, gr.get(l.name + ".bias"))
             else:
                 g = ops.instnorm_lrelu_bwd2(g, skip_g, ctx.raw[i], ctx.stats[i], LRELU)
-            g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0))
+            g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0),
+                             defer=FOLD_IN_NORM and i > 1)           # (layer i-1 has a norm)
             self._mark(self.pG, grp)
             if update:
                 self._update_group(grp, l, hyper_dev)

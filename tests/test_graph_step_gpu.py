@@ -114,3 +114,38 @@ def test_pix2pix_update_in_backward_is_bit_equal_to_the_end_of_step_update(prec,
             assert torch.equal(x, y), f"step {i}"
         for x, y in zip(a[5] + a[6], b[5] + b[6]):
             assert torch.equal(x, y), f"packed operand differs after step {i}"
+
+
+def test_pix2pix_split_k_folded_in_the_norm_is_bit_equal_to_separate_reduce_launches():
+    """The inner levels' split-K convolutions hand their fp32 partial slabs to the InstanceNorm launch that consumes them
+    (forward: the encoder / decoder norms; backward: the incoming gradient of the encoder norms) instead of a reduce launch
+    of their own: same order of additions, same rounding -- losses, every parameter and the saved activations' effect on
+    the next steps bit-equal.  Headline widths at 64 x 64 tiles so that the inner levels really are split."""
+    from stain2stain_amd import PatchGANDiscriminator, Pix2PixGenerator, Pix2PixTrainer, pix2pix_engine, ops
+    data = _batches(3, 4, 64, 9)
+    runs, folded = {}, {}
+    for fold in (False, True):
+        pix2pix_engine.FOLD_IN_NORM = fold
+        count = {"n": 0}
+        orig = ops.instnorm_lrelu_fwd2_split
+
+        def counting(*a, _o=orig, **k):
+            count["n"] += 1
+            return _o(*a, **k)
+        ops.instnorm_lrelu_fwd2_split = counting
+        try:
+            torch.manual_seed(1984)
+            G, D = Pix2PixGenerator(ngf=64, num_downs=6).to(DEV), PatchGANDiscriminator(ndf=16).to(DEV)
+            tr = Pix2PixTrainer(G, D)
+            rec = []
+            for src, tgt, _ in data:
+                rec.append((tr.step(src, tgt).clone(), tr.pG.p.clone(), tr.pD.p.clone()))
+            torch.cuda.synchronize()
+        finally:
+            ops.instnorm_lrelu_fwd2_split = orig
+            pix2pix_engine.FOLD_IN_NORM = True
+        runs[fold], folded[fold] = rec, count["n"]
+    assert folded[False] == 0 and folded[True] >= 3 * 2, folded            # at least two folded norms per forward pass
+    for i, (a, b) in enumerate(zip(runs[True], runs[False])):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), f"step {i}"
