@@ -1280,10 +1280,16 @@ __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict_
   out[i] = accumulate ? out[i] + v : v;
 }
 
+// workgroups the 4x4 weight-gradient launches aim at (S2S_P2P_WGRAD_BLOCKS; see s2s_conv3x3_wgrad_splits)
+int p2p_wgrad_target() {
+  static const int t = [] { const char* e = getenv("S2S_P2P_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();   // (512: 4.07, 384: 4.04, 256: 4.01, 192: 4.28 ms per G + D step on one box)
+  return t;
+}
+
 int conv2x2_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
   const int nt = B * cdiv(H, 8) * cdiv(W, 16);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
-  int s = 512 / mn;
+  int s = p2p_wgrad_target() / mn;
   if (s > 256) s = 256;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
@@ -1304,9 +1310,14 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   const int khm = wgrad_kh_split(dtype, Cin, Cout);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (khm == 1 ? 3 : 1);
   static const int target_env = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int target = target_env ? target_env : (khm == 2 ? 256 : 512);   // one 12-wave or two 4-wave workgroups per CU
-  // at most two resident workgroups per CU (256 CUs) in one wave of blocks; every split costs a |dW| x 4 B partial
-  // slab, so the two-tile layers stop at 320 splits (a single-tile layer takes all 512)
+  // ONE workgroup per CU (256; round 3).  Alone, the kernel is 7 % faster with two per CU (1078 against 1003 TFLOP/s), but
+  // a pair takes every vector register of its CU, and this kernel runs on the side stream UNDER the bandwidth-bound
+  // BatchNorm / up-sampling backward passes of the compute stream: with half of each CU's registers left free those
+  // passes are really co-resident instead of waiting for a CU to drain -- CFM step 7.75 -> 7.50 ms on one box (-3.3 %),
+  // and the split slabs (and their fold: 0.26 -> 0.17 ms per step) halve.  Sweep on one box (ms per step): 512: 7.72-7.77,
+  // 384: 7.58-7.64, 256: 7.45-7.52, 224: 7.49, 192: 7.59, 128: 7.93.  S2S_WGRAD_BLOCKS=512 restores two per CU.
+  const int target = target_env ? target_env : 256;
+  // every split costs a |dW| x 4 B partial slab; the cap only matters for targets above 320
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
   const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
   int s = target / mn;
@@ -1410,7 +1421,7 @@ extern "C" int s2s_conv4x4s1_wgrad_splits(int B, int H, int W, int Cin, int Cout
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = B * cdiv(H, 8) * cdiv(W, 16);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * 4;        // four kernel rows per (co, ci) tile
-  int s = 512 / mn;
+  int s = p2p_wgrad_target() / mn;
   if (s > 128) s = 128;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
@@ -1518,7 +1529,7 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
       a.lgh = __builtin_ctz((unsigned)H); a.lgw = __builtin_ctz((unsigned)W);
       a.ntiles = cdiv(B * H * W, 128);
       const int mn = cdiv(cin, 64) * cdiv(Cout, 64);
-      int sp = 512 / mn;
+      int sp = p2p_wgrad_target() / mn;
       if (sp > a.ntiles) sp = a.ntiles;
       if (sp > a.S) sp = a.S;
       a.S = sp < 1 ? 1 : sp;
