@@ -1321,6 +1321,10 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
   const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
   int s = target / mn;
+  // (a layer whose (co, ci) tiles alone are 3/4 of the target -- 1536 -> 512: 192 tiles -- would leave a quarter of the CUs
+  //  without a workgroup: one more split)
+  static const int fill = [] { const char* e = getenv("S2S_WGRAD_FILL"); return e ? atoi(e) : 1; }();
+  if (fill && s >= 1 && (long)s * mn < (long)target * 7 / 8 && (long)(s + 1) * mn <= 2L * target) s += 1;
   if (s > cap) s = cap;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
