@@ -1867,8 +1867,9 @@ template <int BN, int MODE, int NS = 8>
 int launch_convflat(Conv3x3Args& a, hipStream_t s) {
   constexpr int lds = 2 * 4 * 128 * 64 + NS * BN * 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  if (NS == 8) {       // S2S_FLAT_NS=4: the 3-tap ring of the windowed kernels, for A/B measurements
-    static const int ns_env = [] { const char* e = getenv("S2S_FLAT_NS"); return e ? atoi(e) : 8; }();
+  if (NS == 8) {       // four slots (96 instead of 128 KB of LDS) since round 3: 3.84 against 3.87 ms per G + D step with the
+                       // weight gradients at one workgroup per CU; S2S_FLAT_NS=8: the seven-tap ring
+    static const int ns_env = [] { const char* e = getenv("S2S_FLAT_NS"); return e ? atoi(e) : 4; }();
     if (ns_env == 4) return launch_convflat<BN, MODE, 4>(a, s);
   }
   auto kern = convflat_dma16_kernel<BN, MODE, NS>;
