@@ -1316,7 +1316,7 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   // passes are really co-resident instead of waiting for a CU to drain -- CFM step 7.75 -> 7.50 ms on one box (-3.3 %),
   // and the split slabs (and their fold: 0.26 -> 0.17 ms per step) halve.  Sweep on one box (ms per step): 512: 7.72-7.77,
   // 384: 7.58-7.64, 256: 7.45-7.52, 224: 7.49, 192: 7.59, 128: 7.93.  S2S_WGRAD_BLOCKS=512 restores two per CU.
-  const int target = target_env ? target_env : 256;
+  const int target = target_env ? target_env : 256;   // (384 / 512 for the concat-input layers alone: 7.48 / 7.52 against 7.45 ms)
   // every split costs a |dW| x 4 B partial slab; the cap only matters for targets above 320
   static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
   const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
@@ -1425,7 +1425,10 @@ extern "C" int s2s_conv4x4s1_wgrad_splits(int B, int H, int W, int Cin, int Cout
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = B * cdiv(H, 8) * cdiv(W, 16);
   const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * 4;        // four kernel rows per (co, ci) tile
-  int s = p2p_wgrad_target() / mn;
+  // (the stride-1 PatchGAN layers -- C512 is 129 GFLOP, a fifth of the step's weight-gradient work -- do better at 1.5
+  //  workgroups per CU: 3.82 against 3.85 ms per G + D step; S2S_P2P_WGRAD_S1_BLOCKS)
+  static const int t1 = [] { const char* e = getenv("S2S_P2P_WGRAD_S1_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+  int s = t1 / mn;
   if (s > 128) s = 128;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
