@@ -122,8 +122,9 @@ def test_module_face_fp32_mode_matches_the_oracle_and_runs_on_the_engine_passes(
     fake_o, ld_o, lg_o = O.pix2pix_losses(Go, Do, src, tgt)
     assert type(fake.grad_fn).__name__ == _GeneratorFn.__name__ + "Backward"
     assert type(D(src.to(DEV), tgt.to(DEV)).grad_fn).__name__ == _DiscriminatorFn.__name__ + "Backward"
-    assert float((fake.detach().cpu() - fake_o).abs().max()) < 1e-3 * float(fake_o.abs().max())
-    assert abs(float(ld) - float(ld_o)) < 1e-3 * abs(float(ld_o)) and abs(float(lg) - float(lg_o)) < 1e-3 * abs(float(lg_o))
+    assert float((fake.detach().cpu() - fake_o.detach()).abs().max()) < 1e-3 * float(fake_o.detach().abs().max())
+    ldv, lgv, ldo, lgo = (float(v.detach()) for v in (ld, lg, ld_o, lg_o))
+    assert abs(ldv - ldo) < 1e-3 * abs(ldo) and abs(lgv - lgo) < 1e-3 * abs(lgo)
     (ld + lg).backward()
     (ld_o + lg_o).backward()
     for mod, ref in ((G, Go), (D, Do)):
