@@ -327,9 +327,10 @@ def main() -> None:
                          "all-reduce + full Adam (same results; ddp.GradBucketer mode 'reduce_scatter')")
     ap.add_argument("--breakdown", action="store_true",
                     help="HIP events around EVERY op (per-kernel table; costs ~1 ms/step of host time)")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=16,
                     help="bracket the conv launches of every N-th timed step with HIP events for the roofline leg "
-                         "(1 = every step; the marker packets cost ~10 us per bracketed launch)")
+                         "(1 = every step).  A bracketed step runs on ONE stream so that a bracket times its kernel alone: "
+                         "it takes ~0.9 ms longer than an overlapped step, so N = 8 cost the line 1.4 %%, 16 costs 0.7 %%")
     ap.add_argument("--mode", default="train", choices=["train", "sample", "pix2pix"],
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
@@ -495,7 +496,7 @@ def main() -> None:
     # live HIP-event timing of the dominant kernels inside the timed region.  An event pair is two marker packets on
     # the launch stream (~5 us each side of the kernel, rocprofv3 kernel trace), i.e. ~0.3-0.5 ms per step if all
     # 51 conv launches of every step are bracketed; so the brackets go around every launch of every
-    # --event-every'th step (default 8; 1 = every step) and the per-launch average is taken over those.
+    # --event-every'th step (default 16; 1 = every step) and the per-launch average is taken over those.
     every = 1 if args.breakdown else max(1, args.event_every)
     only = None if args.breakdown else ("conv3x3_mfma", "conv3x3_wgrad_mfma")
     prof, timed_steps = [], 0
