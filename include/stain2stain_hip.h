@@ -61,6 +61,14 @@ int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x
                        const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
                        const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H, int W,
                        int Cout, void* stream);
+/* Rows of BatchNorm partial sums a training-step launch of these operands writes (>= 1): s2s_conv3x3_stat_blocks() of
+ * them, or one per (workgroup, wave row) when the launch runs on the persistent kernel with a single channel tile (the
+ * 64- and 128-channel layers at 256^2 / 128^2: the sums are carried over a workgroup's tiles in registers).  Size
+ * stat_part as float[2][Cout][rows] and hand `rows` to s2s_conv3x3_nhwc_s (stat_rows = 0: the per-tile count). */
+int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int has_bias);
+int s2s_conv3x3_nhwc_s(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1, const void* w_packed,
+                       const float* bias, void* y, int ldy, float* stat_part, int stat_rows, const float* ep_scale,
+                       const float* ep_shift, int relu, float* kwork, int B, int H, int W, int Cout, void* stream);
 int s2s_debug_conv_clock(long* out_host, int n);
 
 /* ---- 3x3 convolution weight gradient (conv3x3_wgrad_mfma.hip) -----------------------------------

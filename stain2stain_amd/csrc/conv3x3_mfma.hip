@@ -78,6 +78,9 @@ struct Conv3x3Args {
   int xsp, xsn;
   long stat_rows;  // rows per channel of stat_part (tiles, or tiles x wave rows with the register epilogue)
   int direct_ep;   // 1: launches without statistics store straight from the accumulators (conv_epilogue16_direct); S2S_CONV_EPI=lds: 0
+  int stat_carry;  // persistent kernel with one channel tile: a wave row's statistics are carried over its tiles and
+                   // written once, row = workgroup * WM + wave row (stat_rows = workgroups * WM)
+  long stat_rows_req;   // rows the caller sized stat_part for (0: tiles * WM / tiles, the per-tile forms)
   int dbg;   // S2S_CONV_DBG: 64 = clock probe, 128 = old LDS slot key; -DS2S_ABLATE builds only: bit0 = no weight DMA in the
              // 32x32x16 loop, bit1 = no MFMA, bit2 = no halo DMA, 8 = no global stores, 16 = no epilogue
 };
@@ -816,10 +819,45 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + BITS, 0xf, 0xf, false));
 }
 
-template <int TH, int TW, int BN, int WM, int WN, bool AFFINE, bool STATS = false>
+// Fold a wave's per-lane statistics over the sixteen pixel lanes of each row (four DPP row rotations) and write the wave
+// row's partial sums: stat_part[which][channel][stat_row].
+template <int BN, int WN>
+__device__ __forceinline__ void conv_stats_flush(const Conv3x3Args& a, float (*s1)[8], float (*s2)[8], int n0, int tid,
+                                                 long stat_row) {
+  constexpr int WTN = BN / WN, NI = WTN / 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, cl = lane & 15, q = lane >> 4;
+  const int nlane = n0 + wn * WTN + (q & 1) * 16 + (q >> 1) * 8;
+#pragma unroll
+  for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float u = s1[pr][k], w2 = s2[pr][k];
+      u = row_ror_add<8>(u); u = row_ror_add<4>(u); u = row_ror_add<2>(u); u = row_ror_add<1>(u);
+      w2 = row_ror_add<8>(w2); w2 = row_ror_add<4>(w2); w2 = row_ror_add<2>(w2); w2 = row_ror_add<1>(w2);
+      s1[pr][k] = u; s2[pr][k] = w2;
+    }
+  if (cl == 0 && stat_row >= 0) {
+#pragma unroll
+    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int n = nlane + pr * 32 + k;
+        if (n < a.Cout) {
+          a.stat_part[((long)n) * a.stat_rows + stat_row] = s1[pr][k];
+          a.stat_part[((long)a.Cout + n) * a.stat_rows + stat_row] = s2[pr][k];
+        }
+      }
+  }
+}
+
+// CARRY (with STATS): the per-lane sums live in the CALLER's registers (cs1 / cs2, zeroed by it) and are neither folded
+// nor stored here -- a persistent workgroup carries them over all of its tiles and calls conv_stats_flush once.
+template <int TH, int TW, int BN, int WM, int WN, bool AFFINE, bool STATS = false, bool CARRY = false>
 __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32x4 (&acc)[(TH * TW / WM) / 16][(BN / WN) / 16],
                                                        const float (&bias)[(BN / WN) / 16][4], int img, int y0, int x0p,
-                                                       int n0, int tid, const OutMap om, long stat_row = -1) {
+                                                       int n0, int tid, const OutMap om, long stat_row = -1,
+                                                       float (*cs1)[8] = nullptr, float (*cs2)[8] = nullptr) {
   using T = bf16_t;
   constexpr int BM = TH * TW, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   static_assert(NI % 2 == 0, "channel blocks are exchanged in pairs");
@@ -839,8 +877,10 @@ __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32
     }
   // after the exchange this lane holds channels [blk * 16 + (q >> 1) * 8, + 8) with blk = ni + (q & 1)
   const int nlane = n0 + wn * WTN + (q & 1) * 16 + (q >> 1) * 8;
-  float s1[STATS ? NI / 2 : 1][8], s2[STATS ? NI / 2 : 1][8];
-  if constexpr (STATS) {
+  float s1l[STATS ? NI / 2 : 1][8], s2l[STATS ? NI / 2 : 1][8];
+  float (*const s1)[8] = CARRY ? cs1 : s1l;
+  float (*const s2)[8] = CARRY ? cs2 : s2l;
+  if constexpr (STATS && !CARRY) {
 #pragma unroll
     for (int pr = 0; pr < NI / 2; ++pr)
 #pragma unroll
@@ -900,29 +940,7 @@ __device__ __forceinline__ void conv_epilogue16_direct(const Conv3x3Args& a, f32
       }
     }
   }
-  if constexpr (STATS) {
-#pragma unroll
-    for (int pr = 0; pr < NI / 2; ++pr)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float u = s1[pr][k], w2 = s2[pr][k];
-        u = row_ror_add<8>(u); u = row_ror_add<4>(u); u = row_ror_add<2>(u); u = row_ror_add<1>(u);
-        w2 = row_ror_add<8>(w2); w2 = row_ror_add<4>(w2); w2 = row_ror_add<2>(w2); w2 = row_ror_add<1>(w2);
-        s1[pr][k] = u; s2[pr][k] = w2;
-      }
-    if (cl == 0 && stat_row >= 0) {
-#pragma unroll
-      for (int pr = 0; pr < NI / 2; ++pr)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int n = nlane + pr * 32 + k;
-          if (n < a.Cout) {
-            a.stat_part[((long)n) * a.stat_rows + stat_row] = s1[pr][k];
-            a.stat_part[((long)a.Cout + n) * a.stat_rows + stat_row] = s2[pr][k];
-          }
-        }
-    }
-  }
+  if constexpr (STATS && !CARRY) conv_stats_flush<BN, WN>(a, s1, s2, n0, tid, stat_row);
 }
 
 // S2S_CONV_DBG=64: thread 0 of each workgroup records the shader-clock counter and the 100 MHz wall clock at entry
@@ -1151,7 +1169,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
 // Every wave issues the same number of DMAs per tap whatever the tile (zero page for padding, ragged edges and "no next
 // tile"), so all `s_waitcnt vmcnt(N)` are compile-time counts.
 // =========================================================================================================
-template <int TH, int TW, int BN, int WM, int WN, int NS, bool STATS>
+// STATS: 0 = none, 1 = one statistics row per (tile, wave row), 2 = carried over the workgroup's tiles (one row per
+// (workgroup, wave row); launches with a single channel tile whose caller sized stat_part that way)
+template <int TH, int TW, int BN, int WM, int WN, int NS, int STATS>
 __global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, int ntiles, int GX, int GY) {
   using T = bf16_t;
   constexpr int HP = TW + 4, HH_ = TH + 2, ROWS = HH_ * HP;
@@ -1163,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, i
   constexpr int RB = TW / 16;
   // VMEM stores a wave issues in one epilogue of a FULL tile: the 16-byte output stores, and with statistics the
   // 2 x 8 x NI/2 partial sums of a row's lane 0 (vmcnt counts stores too; partial tiles drain instead, see below)
-  constexpr int NST = MI * (NI / 2) + (STATS ? (NI / 2) * 16 : 0);
+  constexpr int NST = MI * (NI / 2) + (STATS == 1 ? (NI / 2) * 16 : 0);
   static_assert((NS - 2) * BG + HG + NST <= 63, "vmcnt is a 6-bit counter");
   static_assert(WM * WN == 4 && BN % 64 == 0 && NS == 4 && TW % 16 == 0 && WTM % TW == 0, "configuration");
 
@@ -1338,6 +1358,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, i
     });
     ++gc;
   };
+  // STATS == 2 (one channel tile, the caller sized stat_part for workgroups x WM rows): the statistics of a wave row
+  // stay in registers over all tiles of the workgroup -- per tile only the 2 x 64 accumulations remain, the DPP fold and
+  // the 32 single-lane stores (which the next tile's third tap had to see retired: vmcnt is in order) happen once
+  float cs1[STATS == 2 ? NI / 2 : 1][8], cs2[STATS == 2 ? NI / 2 : 1][8];
+  if constexpr (STATS == 2) {
+#pragma unroll
+    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cs1[pr][k] = 0.f; cs2[pr][k] = 0.f; }
+  }
   for (;;) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1352,7 +1382,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, i
     {
       const OutMap om{1, 0, 0, a.H, a.W};
       const float nobias[NI][4] = {};
-      conv_epilogue16_direct<TH, TW, BN, WM, WN, false, STATS>(a, acc, nobias, cur.img, cur.y0, cur.x0p, cur.n0, tid, om, (long)cur.id * WM + wm);
+      if constexpr (STATS == 2)
+        conv_epilogue16_direct<TH, TW, BN, WM, WN, false, true, true>(a, acc, nobias, cur.img, cur.y0, cur.x0p, cur.n0, tid, om, -1, cs1, cs2);
+      else
+        conv_epilogue16_direct<TH, TW, BN, WM, WN, false, STATS == 1>(a, acc, nobias, cur.img, cur.y0, cur.x0p, cur.n0, tid, om, (long)cur.id * WM + wm);
       // a partial tile (image edge, last channel tile) may skip store instructions whose lanes are all out of range, so
       // its store count is not the compile-time one: drain instead (everything older has then landed, and the larger
       // counts of the next two taps are merely permissive)
@@ -1365,6 +1398,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pers16_kernel(Conv3x3Args a, i
     has_next = L + G < ntiles;
     if (has_next) nxt = locate(L + G);
   }
+  if constexpr (STATS == 2) conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
+}
+
+// Grid and XCD cut of a persistent launch over GX pixel tiles x GY channel tiles (shared with s2s_conv3x3_stat_rows: with
+// one channel tile the statistics take grid * WM rows)
+struct PersPlan { int grid, xsp, xsn; };
+inline PersPlan pers_plan(const Conv3x3Args& a, int GX, int GY) {
+  PersPlan p{1, 0, 1};
+  const long ntiles = (long)GX * GY;
+  if (ntiles % 8 == 0) {
+    const double act = 2.0 * a.B * a.H * a.W * (a.c0 + a.c1), wb = 2.0 * 9 * (a.c0 + a.c1) * a.Cout;
+    double best = 0;
+    for (int sp = 8; sp >= 1; sp >>= 1) {
+      const int sn = 8 / sp;
+      if (GX % sp || GY % sn) continue;
+      const double cost = sn * act + sp * wb;
+      if (!p.xsp || cost < best) { best = cost; p.xsp = sp; p.xsn = sn; }
+    }
+  }
+  static const int slots = [] { const char* e = getenv("S2S_CONV_PERS_WGS"); return e ? atoi(e) : 512; }();   // 2 per CU
+  int grid = (int)(ntiles < slots ? ntiles : slots);
+  if (p.xsp && grid > 8) grid -= grid % 8;             // a stride that is a multiple of 8 keeps a workgroup inside its XCD's block
+  p.grid = grid < 1 ? 1 : grid;
+  return p;
 }
 
 template <int TH, int TW, int BN, int WM, int WN>
@@ -1376,30 +1433,25 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
-  auto kern_s = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, true>;
-  auto kern_d = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, false>;
-  static unsigned long long attr_s = 0, attr_d = 0;   // hipFuncSetAttribute is per device
+  auto kern_s = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, 1>;
+  auto kern_c = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, 2>;
+  auto kern_d = conv3x3_pers16_kernel<TH, TW, BN, WM, WN, NS, 0>;
+  static unsigned long long attr_s = 0, attr_c = 0, attr_d = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_s), lds, &attr_s)) return rc;
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_c), lds, &attr_c)) return rc;
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_d), lds, &attr_d)) return rc;
   const int GX = a.B * a.tilesY * a.tilesX, GY = cdiv(a.Cout, BN);
   const long ntiles = (long)GX * GY;
-  a.stat_rows = (long)GX * WM;
-  a.xsp = 0; a.xsn = 1;
-  if (ntiles % 8 == 0) {
-    const double act = 2.0 * a.B * a.H * a.W * (a.c0 + a.c1), wb = 2.0 * 9 * (a.c0 + a.c1) * a.Cout;
-    double best = 0;
-    for (int sp = 8; sp >= 1; sp >>= 1) {
-      const int sn = 8 / sp;
-      if (GX % sp || GY % sn) continue;
-      const double cost = sn * act + sp * wb;
-      if (!a.xsp || cost < best) { best = cost; a.xsp = sp; a.xsn = sn; }
-    }
-  }
-  static const int slots = [] { const char* e = getenv("S2S_CONV_PERS_WGS"); return e ? atoi(e) : 512; }();   // 2 per CU
-  int grid = (int)(ntiles < slots ? ntiles : slots);
-  if (a.xsp && grid > 8) grid -= grid % 8;             // a stride that is a multiple of 8 keeps a workgroup inside its XCD's block
-  if (grid < 1) grid = 1;
-  if (a.stat_part) hipLaunchKernelGGL(kern_s, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
+  const PersPlan pl = pers_plan(a, GX, GY);
+  a.xsp = pl.xsp; a.xsn = pl.xsn;
+  const int grid = pl.grid;
+  // statistics rows: one per (workgroup, wave row) when the caller sized the buffer for that (s2s_conv3x3_stat_rows) and
+  // there is a single channel tile; else one per (tile, wave row)
+  a.stat_carry = a.stat_part && GY == 1 && a.stat_rows_req == (long)grid * WM;
+  if (a.stat_part && !a.stat_carry && a.stat_rows_req && a.stat_rows_req != (long)GX * WM) return S2S_ERR_SHAPE;
+  a.stat_rows = a.stat_carry ? (long)grid * WM : (long)GX * WM;
+  if (a.stat_carry) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
+  else if (a.stat_part) hipLaunchKernelGGL(kern_s, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
   else hipLaunchKernelGGL(kern_d, dim3(grid), dim3(256), lds, s, a, (int)ntiles, GX, GY);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
@@ -1419,6 +1471,7 @@ int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   if (!a.kpart) a.ksplit = 1;
   dim3 grid(a.B * a.tilesY * a.tilesX, cdiv(a.Cout, BN), a.ksplit);
   a.stat_rows = (long)grid.x * (a.direct_ep ? WM : 1);      // (s2s_conv3x3_stat_blocks reports the same count)
+  if (a.stat_part && a.stat_rows_req && a.stat_rows_req != a.stat_rows) return S2S_ERR_SHAPE;
   static const int xcd_aware = [] { const char* e = getenv("S2S_CONV_XCD"); return e ? atoi(e) : 1; }();
   a.xsp = 0; a.xsn = 1;
   if (xcd_aware && a.ksplit == 1 && ((long)grid.x * grid.y) % 8 == 0) {
@@ -2127,6 +2180,20 @@ int select_cfg(int dtype, int B, int H, int W, int Cout) {
   return best;
 }
 
+// Does this bf16 launch run on the persistent kernel?  (dispatch() and s2s_conv3x3_stat_rows() share the decision: the
+// number of statistics rows follows it.)
+inline bool pers_eligible(const Conv3x3Args& a, int id) {
+  static const int pers = [] { const char* e = getenv("S2S_CONV_PERS"); return e ? atoi(e) : 1; }();
+  // (only where a workgroup gets at least two tiles on average: with one tile each the walk buys nothing and its
+  //  bookkeeping costs 3-10 % -- measured on the 64^2 / 32^2 levels, whose grids are ~512 tiles)
+  if (id == 0 || id == 4) return false;      // 256-pixel x 128-channel tiles spill in the tile walk: one-tile kernel
+  const TileCfg& tc = kBf16Cfg[id];
+  const bool many = cfg_blocks(tc, a.B, a.H, a.W, a.Cout) >= (pers > 1 ? pers : 1024);
+  return pers && many && a.direct_ep && !a.bias && !a.ep_scale && !a.kpart && !a.act && !a.y2 && a.nchunk >= 2 && !(a.dbg & 64) &&
+         a.c0 % 32 == 0 &&                      // a chunk reads one source; 32-bit byte offsets into each source
+         (double)a.B * a.H * a.W * a.ld0 * 2 < 4.0e9 && (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 < 4.0e9;
+}
+
 int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
   const int id = select_cfg(dtype, a.B, a.H, a.W, a.Cout);
   if (dtype == S2S_F32) {
@@ -2165,14 +2232,7 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
 #endif
   // the training step's launches (forward with BatchNorm statistics, data gradients: no bias, no folded affine, no
   // split-K) run on the persistent kernel; S2S_CONV_PERS=0: one tile per workgroup as before
-  static const int pers = [] { const char* e = getenv("S2S_CONV_PERS"); return e ? atoi(e) : 1; }();
-  // (only where a workgroup gets at least two tiles on average: with one tile each the walk buys nothing and its
-  //  bookkeeping costs 3-10 % -- measured on the 64^2 / 32^2 levels, whose grids are ~512 tiles)
-  const TileCfg& tc = kBf16Cfg[id];
-  const bool many = cfg_blocks(tc, a.B, a.H, a.W, a.Cout) >= (pers > 1 ? pers : 1024);
-  if (pers && many && a.direct_ep && !a.bias && !a.ep_scale && !a.kpart && !a.act && !a.y2 && a.nchunk >= 2 && !(a.dbg & 64) &&
-      a.c0 % 32 == 0 &&                      // a chunk reads one source; 32-bit byte offsets into each source
-      (double)a.B * a.H * a.W * a.ld0 * 2 < 4.0e9 && (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 < 4.0e9) {
+  if (pers_eligible(a, id)) {
     switch (id) {      // (the 256-pixel x 128-channel tiles, ids 0 and 4, need 128 accumulator + 48 fragment registers: with the
                        //  tile loop's state they spill, so they stay on the one-tile-per-workgroup kernel)
       case 1: return launch_pers16<8, 32, 64, 4, 1>(a, s);
@@ -2256,6 +2316,10 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
                                   const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
                                   const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
                                   int W, int Cout, void* stream);
+extern "C" int s2s_conv3x3_nhwc_s(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                                  const void* w_packed, const float* bias, void* y, int ldy, float* stat_part, int stat_rows,
+                                  const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
+                                  int W, int Cout, void* stream);
 
 // Split count of s2s_conv3x3_nhwc_k for a launch without statistics (bf16; 1 = not split): at small batch the deep
 // levels have a few dozen output tiles and K = 9 x 512..1536, so the chunk range is shared by up to 16 workgroups.
@@ -2285,8 +2349,55 @@ extern "C" int s2s_conv3x3_nhwc(int dtype, const void* x0, int ld0, int c0, cons
                             nullptr, B, H, W, Cout, stream);
 }
 
+static void conv3x3_fill_args(Conv3x3Args& a, int ld0, int c0, int ld1, int c1, const float* bias, int B, int H, int W,
+                              int Cout) {
+  a.bias = bias;
+  a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0; a.lgh = a.lgw = 0;
+  a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32);
+  a.tilesX = a.tilesY = 0;
+  // S2S_CONV_DBG: 64 = clock probe, 128 = the earlier LDS slot key (both leave the results unchanged); the
+  // result-changing timing ablations (bits 1-32) exist only in -DS2S_ABLATE builds
+  { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return (e ? atoi(e) : 0) & S2S_DBG_MASK; }(); a.dbg = dbg; }
+  a.direct_ep = direct_ep_default();
+}
+
+// Rows of BatchNorm partial sums a TRAINING-step launch (statistics, no folded affine, no split) of these operands
+// writes: s2s_conv3x3_stat_blocks() of them, or -- when the launch runs on the persistent kernel with one channel tile --
+// one per (workgroup, wave row).  Size stat_part as float[2][Cout][rows] and pass `rows` to s2s_conv3x3_nhwc_s.
+extern "C" int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1,
+                                     int has_bias) {
+  const int legacy = s2s_conv3x3_stat_blocks(dtype, B, H, W, Cout);
+  if (legacy < 0 || dtype != S2S_BF16 || c0 <= 0 || c1 < 0) return legacy;
+#ifdef S2S_ABLATE
+  { static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
+    if (use_dma != 16) return legacy; }
+#endif
+  static const int carry = [] { const char* e = getenv("S2S_CONV_STAT_CARRY"); return e ? atoi(e) : 1; }();
+  if (!carry) return legacy;
+  Conv3x3Args a{};
+  static const float one = 1.f;
+  conv3x3_fill_args(a, ld0, c0, ld1, c1, has_bias ? &one : nullptr, B, H, W, Cout);
+  const int id = select_cfg(dtype, B, H, W, Cout);
+  if (!pers_eligible(a, id)) return legacy;
+  const TileCfg& tc = kBf16Cfg[id];
+  const int GX = B * cdiv(H, tc.th) * cdiv(W, tc.tw), GY = cdiv(Cout, tc.bn);
+  if (GY != 1) return legacy;
+  static const int wm_of[8] = {2, 4, 2, 2, 2, 4, 2, 2};
+  return pers_plan(a, GX, GY).grid * wm_of[id];
+}
+
 extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
                                   const void* w_packed, const float* bias, void* y, int ldy, float* stat_part,
+                                  const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
+                                  int W, int Cout, void* stream) {
+  return s2s_conv3x3_nhwc_s(dtype, x0, ld0, c0, x1, ld1, c1, w_packed, bias, y, ldy, stat_part, 0, ep_scale, ep_shift, relu,
+                            kwork, B, H, W, Cout, stream);
+}
+
+// stat_rows: the row count stat_part was sized for (s2s_conv3x3_stat_rows), 0 = s2s_conv3x3_stat_blocks() of them
+extern "C" int s2s_conv3x3_nhwc_s(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,
+                                  const void* w_packed, const float* bias, void* y, int ldy, float* stat_part, int stat_rows,
                                   const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H,
                                   int W, int Cout, void* stream) {
   if (!x0 || !w_packed || !y) return S2S_ERR_NULL;
@@ -2297,16 +2408,11 @@ extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, co
   if ((ep_scale == nullptr) != (ep_shift == nullptr)) return S2S_ERR_NULL;
   const uintptr_t al = 15;
   if (((uintptr_t)x0 & al) || ((uintptr_t)x1 & al) || ((uintptr_t)w_packed & al) || ((uintptr_t)y & al)) return S2S_ERR_ALIGN;
+  if (stat_rows < 0) return S2S_ERR_SHAPE;
   Conv3x3Args a{};
-  a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.y = y; a.stat_part = stat_part;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.act = 0; a.act_slope = 0.f; a.y2 = nullptr; a.ldy2 = 8; a.bias_mod = Cout; a.kpart = nullptr; a.ksplit = 1; a.lgc = 0; a.lgh = a.lgw = 0;
-  a.ld0 = ld0; a.c0 = c0; a.ld1 = ld1; a.c1 = c1; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.nchunk = cdiv(c0 + c1, 32); a.relu = relu;
-  a.tilesX = a.tilesY = 0;
-  // S2S_CONV_DBG: 64 = clock probe, 128 = the earlier LDS slot key (both leave the results unchanged); the
-  // result-changing timing ablations (bits 1-32) exist only in -DS2S_ABLATE builds
-  { static const int dbg = [] { const char* e = getenv("S2S_CONV_DBG"); return (e ? atoi(e) : 0) & S2S_DBG_MASK; }(); a.dbg = dbg; }
-  a.direct_ep = direct_ep_default();
+  conv3x3_fill_args(a, ld0, c0, ld1, c1, bias, B, H, W, Cout);
+  a.x0 = x0; a.x1 = x1; a.w = w_packed; a.y = y; a.stat_part = stat_part; a.stat_rows_req = stat_part ? stat_rows : 0;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ldy = ldy; a.relu = relu;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   a.ksplit = (kwork && !stat_part) ? s2s_conv3x3_ksplit(dtype, B, H, W, Cout, c0 + c1) : 1;

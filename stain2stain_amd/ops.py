@@ -35,6 +35,23 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+def _quiesce_at_exit() -> None:
+    """Before the interpreter tears anything down: destroy unreachable captured graphs (they live in reference cycles with
+    their trainers) and let the device drain, while torch's and the HIP runtime's state are still complete."""
+    import gc
+    gc.collect()
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:  # noqa: BLE001 -- nothing useful can be done about a failing device at exit
+        pass
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_quiesce_at_exit)
+
+
 def _stream() -> int:
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
@@ -251,16 +268,17 @@ def conv3x3(x0: torch.Tensor, x1: Optional[torch.Tensor], w_packed: torch.Tensor
     elif out.shape != (B, H, W, cout) or out.dtype != x0.dtype:
         raise RuntimeError("stain2stain_amd: conv3x3 output buffer mismatch")
     py, ldy = _nhwc(out)
-    stat = None
+    stat, nb = None, 0
     if want_stats:
-        nb = _L().s2s_conv3x3_stat_blocks(dt, B, H, W, cout)
+        nb = _L().s2s_conv3x3_stat_rows(dt, B, H, W, cout, c0, c1, ld0, ld1, int(bias is not None))
+        _native.check(min(nb, 0), "conv3x3_stat_rows")
         stat = torch.empty((2, cout, nb), dtype=torch.float32, device=x0.device)
     kwork = None
     if not want_stats:                    # few output tiles (small batches): the chunk range is split over workgroups
         nsplit = _L().s2s_conv3x3_ksplit(dt, B, H, W, cout, c0 + c1)
         if nsplit > 1:
             kwork = torch.empty((nsplit, B * H * W, cout), dtype=torch.float32, device=x0.device)
-    rc = _L().s2s_conv3x3_nhwc_k(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat),
+    rc = _L().s2s_conv3x3_nhwc_s(dt, p0, ld0, c0, p1, ld1, c1, _ptr(w_packed), _f32(bias), py, ldy, _f32(stat), nb,
                                  _f32(scale), _f32(shift), int(relu), _f32(kwork), B, H, W, cout, _stream())
     _native.check(rc, "conv3x3")
     return out, stat
