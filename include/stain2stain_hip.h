@@ -344,6 +344,24 @@ int s2s_conv4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* w
 int s2s_convt4x4s2_ksplit(int B, int h, int w, int C, int Cin);
 int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* wd, const float* bias, void* y, int ldy,
                         float* kwork, int B, int h, int w, int C, void* stream);
+/* The same two layers on the generator's INNER levels as ONE launch with what follows them (conv_small.hip; bf16):
+ * a workgroup owns whole samples x 16 output channels and all of K, so there is no split-K, no partial slab and no
+ * reduce, and InstanceNorm + activation (forward) or their backward (data gradient) are the epilogue.
+ *   mode 1: nn.Conv2d(4, 2, 1) from the plain x [B][2h][2w][Cin] with wf -> [B][h][w][Cout], h * w <= 64;
+ *   mode 2: nn.ConvTranspose2d(4, 2, 1) / the convolution's data gradient from x [B][h][w][Cin] with wd ->
+ *           [B][2h][2w][Cout], h * w <= 16.   h, w powers of two, Cin % 32 == 0 (Cin / 32 <= 8 or a multiple of 8),
+ *           Cout % 16 == 0; s2s_convsm_ok() != 0 says a shape is taken.
+ *   epi 0: y = act ? lrelu(conv + bias, slope) : conv + bias; y2 (optional) = relu(y).
+ *   epi 1: raw (optional) = bf16(conv + bias); stats[4][B][Cout] = mean, invstd, invstd, -mean * invstd of raw per
+ *          (sample, channel) [InstanceNorm2d(affine=False, eps)]; y = lrelu(norm(raw), slope); y2 (optional) = relu(norm).
+ *   epi 2: g = conv (no bias).  Output channels [0, bwd_c0): y2 = g (pixel stride ldy2, channel index unchanged).
+ *          Output channels [bwd_c0, Cout), as channel c - bwd_c0 of z / stats_in / g2 / y: the backward of epi 1 for
+ *          that tensor, dzn = norm(z) > 0 ? g + g2 : slope * g, y = invstd * (dzn - mean(dzn) - xhat * mean(dzn xhat)). */
+int s2s_convsm_ok(int dtype, int mode, int B, int h, int w, int Cin, int Cout);
+int s2s_convsm_nhwc(int dtype, int mode, const void* x, int ldx, int Cin, const void* w_packed, const float* bias, int epi,
+                    int act, float slope, float eps, void* raw, int ldraw, void* y, int ldy, void* y2, int ldy2,
+                    float* stats, const float* stats_in, const void* z, int ldz, const void* g2, int ldg2, int bwd_c0,
+                    int B, int h, int w, int Cout, void* stream);
 /* InstanceNorm + LeakyReLU with a second output y2 = relu(z) (pixel stride ldy2, optional) and, backward, a second
  * incoming gradient g2 (wrt y2, optional): dz = z > 0 ? g + g2 : slope * g.  Otherwise as s2s_instnorm_lrelu_fwd/bwd. */
 int s2s_instnorm_lrelu_fwd2(int dtype, const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libstain2stain_hip.so")
 # scripts/ only: the same sources with -DS2S_ABLATE (superseded forward loops, result-changing timing ablations)
 ABLATE_LIB_PATH = os.path.join(HERE, "libstain2stain_hip_ablate.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "stain2stain_hip.h")
-SOURCES = ["conv3x3_mfma.hip", "conv3x3_wgrad_mfma.hip", "conv_edge.hip", "norm_act.hip", "resample.hip",
+SOURCES = ["conv3x3_mfma.hip", "conv3x3_wgrad_mfma.hip", "conv_small.hip", "conv_edge.hip", "norm_act.hip", "resample.hip",
            "flow.hip", "optim.hip", "input_pipeline.hip", "seg_loss.hip", "loss_variants.hip", "instnorm.hip", "pix2pix.hip",
            "runtime.hip"]
 

@@ -959,6 +959,121 @@ __global__ __launch_bounds__(256, 1) void conv2x2_wgrad_flat_kernel(WgradArgs a)
   }
 }
 
+// DIRECT form of the flat kernel for the same inner levels when the whole batch is at most 1024 pixels: no split over
+// workgroups (the reduction is 16 ... 1024 pixels long), so there are no partial slabs and no fold launch -- the
+// workgroup writes nn.Conv2d's [Cout][C][4][4] block itself.  For that it has to own all sixteen taps of its (o, c)
+// pairs: its 64 virtual input channels are the four (r, s) sub-pixel groups of SIXTEEN real channels (the flat kernel
+// takes 64 consecutive virtual channels = one (r, s) of 64 real ones, a quarter of every 64-byte [4][4] block), and the
+// 64 x 16 x 16 tile leaves through LDS as 64 rows of 1 KiB.  Double-buffered over the (at most eight) pixel tiles.
+__global__ __launch_bounds__(256, 1) void conv2x2_wgrad_small_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
+  using T = bf16_t;
+  constexpr int NT = 4, NPX = 128;
+  constexpr int DY_BYTES = 2 * NPX * 64, PLANE = NPX * 64, X_BYTES = 2 * NT * PLANE, BUF = DY_BYTES + X_BYTES;
+  constexpr int DYG = 2 * NPX / 16 / 4;                  // 4
+  constexpr int XG = 2 * NT * NPX / 16 / 4;              // 16
+  constexpr int KSTEPS = NPX / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]; the first 64 KiB again for the output tile
+  const T* __restrict__ dy = static_cast<const T*>(a.dy);
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int c0 = blockIdx.x * 16, co0 = blockIdx.y * 64;
+  const int C = a.c0 >> 2;                                // real input channels
+  const int h = 1 << a.lgh, w = 1 << a.lgw;
+  const int npix = a.B << (a.lgh + a.lgw);
+  const int drow = lane >> 2, dslot = lane & 3;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p4 * 4) * 2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  auto dma_tile = [&](int tile, int buf) {
+    const int p0 = tile * NPX;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < DYG; ++j) {
+      const int grp = wave + 4 * j;
+      const int half = grp / (NPX / 16), m = (grp % (NPX / 16)) * 16 + drow;
+      const int co = co0 + half * 32 + dslot * 8, p = p0 + m;
+      const void* src = g_wgrad_zero_page;
+      if (p < npix && co < a.Cout) src = dy + (long)p * a.lddy + co;
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + grp * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < XG; ++j) {
+      const int grp = wave + 4 * j;                          // 64 groups: [half][tap][8 groups of 16 pixels]
+      const int half = grp >> 5, tap = (grp >> 3) & 3, m = (grp & 7) * 16 + drow;
+      const int vci = half * 32 + dslot * 8, rs = vci >> 4, cc = c0 + (vci & 15), p = p0 + m;
+      const void* src = g_wgrad_zero_page;
+      if (p < npix && cc < C) {
+        const int n = p >> (a.lgh + a.lgw), iy = (p >> a.lgw) & (h - 1), ix = p & (w - 1);
+        const int py = 2 * (iy + (tap >> 1)) + (rs >> 1) - 1, px = 2 * (ix + (tap & 1)) + (rs & 1) - 1;
+        if ((unsigned)py < (unsigned)(2 * h) && (unsigned)px < (unsigned)(2 * w))
+          src = x0 + ((long)(n * 2 * h + py) * (2 * w) + px) * a.ld0 + cc;
+      }
+      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + grp * 1024));
+    }
+  };
+
+  int buf = 0;
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int tile = 0; tile < a.ntiles; ++tile) {
+    if (tile + 1 < a.ntiles) dma_tile(tile + 1, buf ^ 1);
+    const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (NT * PLANE) + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16;
+      const bf16x8 af = tr_frag(Ahi + m0 * 64, 4 * 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 bfr = tr_frag(Bhi + t * PLANE + m0 * 64, 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // the next tile has landed and every wave is done with this one
+    buf ^= 1;
+  }
+  // [64 o][16 c][4][4] through LDS: lane = (virtual channel r -> (rs, c), half hh of the co pattern)
+  float* const stg = reinterpret_cast<float*>(smem);
+  const int r = lane & 31, hh = lane >> 5;
+  const int rs = wci * 2 + (r >> 4), c = r & 15;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int t16 = (2 * (t >> 1) + (rs >> 1)) * 4 + 2 * (t & 1) + (rs & 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+      stg[(col * 16 + c) * 16 + t16] = acc[t][j];
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int pi = tid + k * 256, col = pi >> 6, qq = pi & 63;
+    if (co0 + col < a.Cout) {
+      float* const dst = grad + ((long)(co0 + col) * C + c0) * 16 + qq * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + col * 256 + qq * 4);
+      if (accumulate) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += o[i];
+      }
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+}
+
 // KS x KS taps, stride 1 (row a13: the PatchGAN's 4x4 stride-1 pad-1 layers, KS = 4, PAD = 1):
 //   dW[kh*KS+kw][co][ci] = sum_{n,i,j} dY[n][i][j][co] * X[n][i+kh-PAD][j+kw-PAD][ci],   X is (H+KS-1-2PAD) wide.
 // Sixteen 32x32 accumulators do not fit a wave, so the kernel rows go to KS workgroups (blockIdx.z = split*KS + kh,
@@ -1535,6 +1650,16 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
       a.lgc = __builtin_ctz((unsigned)(cin / 4));
       a.lgh = __builtin_ctz((unsigned)H); a.lgw = __builtin_ctz((unsigned)W);
       a.ntiles = cdiv(B * H * W, 128);
+      if (layout == 1 && a.ntiles <= 8 && ((cin / 4) % 16) == 0) {
+        // at most 1024 pixels in the whole batch: one workgroup per (64 o, 16 c) block reduces all of them and writes the
+        // [Cout][C][4][4] gradient itself -- no slabs, no fold launch
+        constexpr int lds_small = 2 * (2 * 128 * 64 + 2 * 4 * 128 * 64);
+        static unsigned long long attr_small = 0;   // hipFuncSetAttribute is per device
+        if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(conv2x2_wgrad_small_kernel), lds_small, &attr_small)) return rc2;
+        hipLaunchKernelGGL(conv2x2_wgrad_small_kernel, dim3(cin / 64, cdiv(Cout, 64)), dim3(256), lds_small, s, a, grad, accumulate);
+        S2S_LAUNCH_CHECK();
+        return S2S_OK;
+      }
       const int mn = cdiv(cin, 64) * cdiv(Cout, 64);
       int sp = p2p_wgrad_target() / mn;
       if (sp > a.ntiles) sp = a.ntiles;

@@ -1346,3 +1346,97 @@ def convT4x4s2(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
                                   h, w, cout, _stream())
     _native.check(rc, "convT4x4s2")
     return SplitSum(kwork, bias, (B, 2 * h, 2 * w, cout), x.dtype) if defer else y
+
+
+# ------------------------------------------------------------------------------------------------
+# the generator's inner levels: convolution + InstanceNorm / activation (or their backward) in one launch (conv_small.hip)
+# ------------------------------------------------------------------------------------------------
+def convsm_ok(dtype: torch.dtype, mode: int, B: int, h: int, w: int, cin: int, cout: int) -> bool:
+    """Does s2s_convsm_nhwc take this layer?  mode 1: h x w = output map of the stride-2 convolution; mode 2: input map of
+    the transposed form."""
+    return dtype == torch.bfloat16 and bool(_L().s2s_convsm_ok(BF16, int(mode), int(B), int(h), int(w), int(cin), int(cout)))
+
+
+def _convsm_flops(mode, x, w_packed, bias, cout, **kw) -> float:
+    B, hi, wi, cin = x.shape
+    return 2.0 * B * (hi // 2) * (wi // 2) * cout * 16 * cin if mode == 1 else 2.0 * B * 4 * hi * wi * cout * 4 * cin
+
+
+def _convsm_shapes(mode: int, x: torch.Tensor, w_packed: torch.Tensor, cout: int):
+    B, hi, wi, cin = x.shape
+    if x.dtype != torch.bfloat16 or w_packed.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: convsm wants bf16 operands")
+    if mode == 1:
+        if hi % 2 or wi % 2:
+            raise RuntimeError("stain2stain_amd: convsm mode 1 wants an even input size")
+        h, w, Ho, Wo = hi // 2, wi // 2, hi // 2, wi // 2
+    else:
+        h, w, Ho, Wo = hi, wi, 2 * hi, 2 * wi
+    if w_packed.numel() != 16 * cin * cout:
+        raise RuntimeError("stain2stain_amd: convsm packed weight does not match (cin, cout)")
+    if not convsm_ok(x.dtype, mode, B, h, w, cin, cout):
+        raise RuntimeError("stain2stain_amd: convsm does not take this shape (see s2s_convsm_ok)")
+    return B, h, w, Ho, Wo, cin
+
+
+@_timed("convkxk_mfma", _convsm_flops)
+def convsm_fwd(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, *,
+               norm: bool, slope: float = 0.0, act: bool = False, out: Optional[torch.Tensor] = None,
+               out2: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """One launch for conv (mode 1: Conv2d(4, 2, 1) of the plain x; mode 2: ConvTranspose2d(4, 2, 1)) + bias and
+    ``norm``: InstanceNorm + LeakyReLU(slope) -> (y, raw, stats) with out2 (optional view) = relu(norm(raw)); else
+    (y, None, None) with y = act ? lrelu(conv + bias, slope) : conv + bias and out2 = relu(y)."""
+    B, h, w, Ho, Wo, cin = _convsm_shapes(mode, x, w_packed, cout)
+    px, ldx = _nhwc(x)
+    y = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device) if out is None else out
+    if tuple(y.shape) != (B, Ho, Wo, cout) or y.dtype != x.dtype:
+        raise RuntimeError("stain2stain_amd: convsm output buffer mismatch")
+    py, ldy = _nhwc(y)
+    p2, ld2 = 0, 8
+    if out2 is not None:
+        if tuple(out2.shape) != (B, Ho, Wo, cout) or out2.dtype != x.dtype:
+            raise RuntimeError("stain2stain_amd: convsm second output mismatch")
+        p2, ld2 = _nhwc(out2)
+    raw = stats = None
+    if norm:
+        raw = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+        stats = torch.empty((4, B, cout), dtype=torch.float32, device=x.device)
+    rc = _L().s2s_convsm_nhwc(BF16, int(mode), px, ldx, cin, _ptr(w_packed), _f32(bias), 1 if norm else 0, int(act),
+                              float(slope), float(eps), _ptr(raw), cout, py, ldy, p2, ld2, _f32(stats), 0, 0, 8, 0, 8, 0,
+                              B, h, w, cout, _stream())
+    _native.check(rc, "convsm_fwd")
+    return y, raw, stats
+
+
+@_timed("convkxk_mfma", lambda mode, g, w_packed, cout, **kw: _convsm_flops(mode, g, w_packed, None, cout))
+def convsm_bwd(mode: int, g: torch.Tensor, w_packed: torch.Tensor, cout: int, *, z: Optional[torch.Tensor],
+               stats: Optional[torch.Tensor], g2: Optional[torch.Tensor], slope: float, bwd_c0: int = 0):
+    """Data gradient (mode 2 with wd: of a stride-2 convolution; mode 1 with wf: of a transposed one) of ``cout`` channels
+    ending in the InstanceNorm + activation backward of the tensor those channels belong to: channels [bwd_c0, cout) are
+    the gradient wrt lrelu(norm(z), slope) (plus ``g2`` wrt relu(norm(z))) and come back as dz; channels [0, bwd_c0) come
+    back as they are (the skip half of a decoder input).  Returns (dz or None, plain or None)."""
+    B, h, w, Ho, Wo, cin = _convsm_shapes(mode, g, w_packed, cout)
+    pg, ldg = _nhwc(g)
+    C2 = cout - bwd_c0
+    dz = plain = None
+    pz = ldz = ps = p2 = 0
+    ldz = ld2 = 8
+    pdz, lddz, ppl, ldpl = 0, 8, 0, 8
+    if C2 > 0:
+        if z is None or stats is None or tuple(z.shape) != (B, Ho, Wo, C2) or tuple(stats.shape) != (4, B, C2):
+            raise RuntimeError("stain2stain_amd: convsm_bwd wants z [B,H,W,C] and stats [4,B,C] of the normed tensor")
+        pz, ldz = _nhwc(z)
+        ps = _f32(stats)
+        if g2 is not None:
+            if tuple(g2.shape) != (B, Ho, Wo, C2) or g2.dtype != g.dtype:
+                raise RuntimeError("stain2stain_amd: convsm_bwd second gradient mismatch")
+            p2, ld2 = _nhwc(g2)
+        dz = torch.empty((B, Ho, Wo, C2), dtype=g.dtype, device=g.device)
+        pdz, lddz = _nhwc(dz)
+    if bwd_c0 > 0:
+        plain = torch.empty((B, Ho, Wo, bwd_c0), dtype=g.dtype, device=g.device)
+        ppl, ldpl = _nhwc(plain)
+    rc = _L().s2s_convsm_nhwc(BF16, int(mode), pg, ldg, cin, _ptr(w_packed), 0, 2, 0, float(slope), 0.0, 0, 8, pdz, lddz,
+                              ppl, ldpl, 0, ps, pz, ldz, p2, ld2, int(bwd_c0), B, h, w, cout, _stream())
+    _native.check(rc, "convsm_bwd")
+    return dz, plain

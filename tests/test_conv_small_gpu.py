@@ -1,0 +1,156 @@
+"""The sample-complete kernels of the pix2pix generator's inner levels (conv_small.hip: convolution + InstanceNorm /
+activation, or the data gradient + their backward, in one launch; conv2x2_wgrad_small_kernel: weight gradient without
+slabs) against torch's own layers in fp32 on the CPU, on bf16-rounded operands (row a13: builder-authored oracle)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPS = 1e-5
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _nhwc(t):           # NCHW fp32 (CPU) -> NHWC bf16 on the GPU
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def _nchw(t):           # NHWC GPU tensor -> NCHW fp32 on the CPU
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _inorm(z):
+    mu = z.mean(dim=(2, 3), keepdim=True)
+    var = z.var(dim=(2, 3), unbiased=False, keepdim=True)
+    return (z - mu) / torch.sqrt(var + EPS), mu[:, :, 0, 0], 1.0 / torch.sqrt(var + EPS)[:, :, 0, 0]
+
+
+def _stats(z_nchw):
+    """stats[4][B][C] as the forward kernels leave them."""
+    _, mu, inv = _inorm(z_nchw)
+    return torch.stack([mu, inv, inv, -mu * inv]).contiguous().to(DEV)
+
+
+def _pack(w, stride=2):
+    from stain2stain_amd import ops
+    return ops.pack_conv4x4_t(w.to(DEV), stride, torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,ho,cin,cout,slope", [(16, 4, 512, 512, 0.2), (16, 2, 512, 512, 0.2), (3, 8, 64, 32, 0.2),
+                                                 (5, 4, 128, 48, 0.0), (2, 2, 256, 16, 0.2)])
+def test_conv_norm_forward(B, ho, cin, cout, slope):
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + ho)
+    x = _rb(torch.randn(B, cin, 2 * ho, 2 * ho, generator=g))
+    w = _rb(torch.randn(cout, cin, 4, 4, generator=g) / (4.0 * cin ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.1
+    wf, _ = _pack(w)
+    skip = torch.full((B, ho, ho, 2 * cout), 7.0, dtype=torch.bfloat16, device=DEV)
+    y, raw, st = ops.convsm_fwd(1, _nhwc(x), wf, b.to(DEV), cout, norm=True, slope=slope, out2=skip[..., :cout])
+    z = _rb(F.conv2d(x, w, b, stride=2, padding=1))
+    zn, mu, inv = _inorm(z)
+    assert _rel(_nchw(raw), z) < 1e-2
+    assert _rel(st[0].cpu(), mu) < 5e-3 and _rel(st[1].cpu(), inv) < 5e-3
+    assert _rel(_nchw(y), F.leaky_relu(zn, slope)) < 2e-2
+    assert _rel(_nchw(skip[..., :cout]), F.relu(zn)) < 2e-2
+    assert float((skip[..., cout:].float() - 7.0).abs().max()) == 0.0          # the other half of the buffer is untouched
+
+
+def test_innermost_conv_relu_forward_skips_dead_taps():
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, cin, cout = 16, 512, 512
+    x = _rb(torch.randn(B, cin, 2, 2, generator=g))
+    w = _rb(torch.randn(cout, cin, 4, 4, generator=g) / 50.0)
+    b = torch.randn(cout, generator=g) * 0.1
+    wf, _ = _pack(w)
+    y, raw, st = ops.convsm_fwd(1, _nhwc(x), wf, b.to(DEV), cout, norm=False, act=True, slope=0.0)
+    assert raw is None and st is None
+    assert _rel(_nchw(y), F.relu(F.conv2d(x, w, b, stride=2, padding=1))) < 1e-2
+
+
+@pytest.mark.parametrize("B,hi,cin,cout", [(16, 4, 1024, 512), (16, 2, 1024, 512), (16, 1, 512, 512), (5, 2, 64, 32),
+                                           (3, 1, 128, 16)])
+def test_transposed_conv_norm_forward(B, hi, cin, cout):
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(B * 10 + hi)
+    x = _rb(torch.randn(B, cin, hi, hi, generator=g))
+    w = _rb(torch.randn(cin, cout, 4, 4, generator=g) / (2.0 * cin ** 0.5))        # nn.ConvTranspose2d layout
+    b = torch.randn(cout, generator=g) * 0.1
+    _, wd = _pack(w)
+    y, raw, st = ops.convsm_fwd(2, _nhwc(x), wd, b.to(DEV), cout, norm=True, slope=0.0)
+    z = _rb(F.conv_transpose2d(x, w, b, stride=2, padding=1))
+    zn, mu, inv = _inorm(z)
+    assert _rel(_nchw(raw), z) < 1e-2
+    assert _rel(st[0].cpu(), mu) < 5e-3 and _rel(st[1].cpu(), inv) < 5e-3
+    assert _rel(_nchw(y), F.relu(zn)) < 2e-2
+
+
+@pytest.mark.parametrize("B,h,cin,cout,with_g2", [(16, 4, 512, 512, True), (16, 2, 512, 512, True), (16, 1, 512, 512, True),
+                                                  (3, 2, 64, 32, False)])
+def test_conv_data_gradient_ends_in_the_norm_backward(B, h, cin, cout, with_g2):
+    """a = lrelu(IN(z)), r = relu(IN(z)); next = conv_s2(a): the launch takes d(next) and returns dz."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(B + h)
+    z = _rb(torch.randn(B, cin, 2 * h, 2 * h, generator=g)).requires_grad_(True)
+    w = _rb(torch.randn(cout, cin, 4, 4, generator=g) / (4.0 * cin ** 0.5))
+    G = _rb(torch.randn(B, cout, h, h, generator=g))
+    G2 = _rb(torch.randn(B, cin, 2 * h, 2 * h, generator=g)) if with_g2 else None
+    zn, _, _ = _inorm(z)
+    loss = (F.conv2d(F.leaky_relu(zn, 0.2), w, None, stride=2, padding=1) * G).sum()
+    if with_g2:
+        loss = loss + (F.relu(zn) * G2).sum()
+    loss.backward()
+    _, wd = _pack(w)
+    dz, plain = ops.convsm_bwd(2, _nhwc(G), wd, cin, z=_nhwc(z.detach()), stats=_stats(z.detach()),
+                               g2=None if G2 is None else _nhwc(G2), slope=0.2)
+    assert plain is None
+    assert _rel(_nchw(dz), z.grad) < 2e-2
+
+
+@pytest.mark.parametrize("B,h,C,cout", [(16, 4, 512, 512), (16, 2, 512, 512), (16, 1, 512, 512), (3, 2, 32, 32)])
+def test_transposed_data_gradient_splits_into_skip_and_norm_backward(B, h, C, cout):
+    """up = convT([skip | relu(IN(zu))]): the launch takes d(up) and returns (dzu, d skip)."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + h)
+    skip = _rb(torch.randn(B, C, h, h, generator=g)).requires_grad_(True)
+    zu = _rb(torch.randn(B, C, h, h, generator=g)).requires_grad_(True)
+    w = _rb(torch.randn(2 * C, cout, 4, 4, generator=g) / (2.0 * (2 * C) ** 0.5))
+    G = _rb(torch.randn(B, cout, 2 * h, 2 * h, generator=g))
+    if h > 1:
+        zn, _, _ = _inorm(zu)
+        (F.conv_transpose2d(torch.cat([skip, F.relu(zn)], 1), w, None, stride=2, padding=1) * G).sum().backward()
+        wf, _ = _pack(w)
+        dz, plain = ops.convsm_bwd(1, _nhwc(G), wf, 2 * C, z=_nhwc(zu.detach()), stats=_stats(zu.detach()), g2=None,
+                                   slope=0.0, bwd_c0=C)
+        assert _rel(_nchw(dz), zu.grad) < 2e-2
+        assert _rel(_nchw(plain), skip.grad) < 1e-2
+    else:       # a 1x1 map has no InstanceNorm: the whole data gradient is plain
+        (F.conv_transpose2d(torch.cat([skip, zu], 1), w, None, stride=2, padding=1) * G).sum().backward()
+        wf, _ = _pack(w)
+        dz, plain = ops.convsm_bwd(1, _nhwc(G), wf, 2 * C, z=None, stats=None, g2=None, slope=0.0, bwd_c0=2 * C)
+        assert dz is None
+        assert _rel(_nchw(plain), torch.cat([skip.grad, zu.grad], 1)) < 1e-2
+
+
+@pytest.mark.parametrize("B,h,cs,cl", [(16, 4, 512, 512), (16, 1, 512, 512), (16, 8, 64, 128), (3, 2, 1024, 16), (16, 2, 96, 64)])
+def test_weight_gradient_without_slabs(B, h, cs, cl):
+    """dW[o][c][4][4] of Conv2d(4, 2, 1) from dy [B,h,h,o] and the plain x [B,2h,2h,c] (<= 1024 pixels: no split, no fold)."""
+    from stain2stain_amd import ops
+    g = torch.Generator().manual_seed(B * 3 + h)
+    x = _rb(torch.randn(B, cl, 2 * h, 2 * h, generator=g))
+    dy = _rb(torch.randn(B, cs, h, h, generator=g))
+    w = torch.zeros(cs, cl, 4, 4, requires_grad=True)
+    (F.conv2d(x, w, None, stride=2, padding=1) * dy).sum().backward()
+    grad = torch.full((cs, cl, 4, 4), 3.0, dtype=torch.float32, device=DEV)
+    ops.convkxk_wgrad(_nhwc(dy), _nhwc(x), grad, 2, x_plain=True)
+    assert _rel(grad.cpu(), w.grad) < 4e-3
+    ops.convkxk_wgrad(_nhwc(dy), _nhwc(x), grad, 2, accumulate=True, x_plain=True)
+    assert _rel(grad.cpu(), 2 * w.grad) < 4e-3
