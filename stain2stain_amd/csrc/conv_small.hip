@@ -13,11 +13,12 @@
 // the InstanceNorm + activation backward of the layer that PRODUCED the convolution's input (the data gradient's output
 // tensor), which needs the same per-(sample, channel) sums.
 //
-// Loop.  K is cut over the 8 waves of the workgroup (each wave owns a contiguous range of the 32-channel chunks for
-// every tap), so nothing is shared between waves until the end and the main loop has no barrier and no LDS: a wave
-// streams its weight fragments (16 output channels x 32 k = 1 KiB contiguous in the packed operand) and its pixel
-// fragments (16 pixel rows x 64 B, im2col formed in the per-lane address) straight into registers through an 8-deep ring
-// of plain global loads, one v_mfma_f32_16x16x32_bf16 per (weight fragment, pixel block).  Operand order as everywhere
+// Loop.  K is cut over the 8 waves of the workgroup by TAP (mode 1: wave w takes taps w, w + 8; mode 2: wave w takes
+// sub-pixel phase w & 3 and two of its four taps), so nothing is shared between waves until the end and the main loop
+// has no barrier and no LDS: per tap the im2col addresses are formed once and the chunk loop only advances pointers; a
+// wave streams its weight fragments (16 output channels x 32 k = 1 KiB contiguous in the packed operand) and its pixel
+// fragments (16 pixel rows x 64 B) straight into registers through an 8-deep ring of plain global loads, one
+// v_mfma_f32_16x16x32_bf16 per (weight fragment, pixel block).  Operand order as everywhere
 // (weights as A, pixels as B): a lane's four accumulator registers are four consecutive channels of one pixel.  The
 // eight partial tiles meet in LDS once.
 //
@@ -55,7 +56,7 @@ struct SmallArgs {
   int B, lgh, lgw;            // MODE 1: h x w = output map; MODE 2: h x w = input map
   int Cout;                   // output channels of the launch (gridDim.y * 16)
   int SG;                     // samples per workgroup (SG * rows per sample <= 16 * NB)
-  int nchunk, U;              // Cin / 32; chunks per wave
+  int nchunk;                 // Cin / 32
   int lgntx;
   int t0y, nty, t0x, ntx;     // live taps: MODE 1 kernel rows t0y .. t0y + nty - 1 (of 4), columns likewise;
                               // MODE 2: nty / ntx = live taps per phase and axis (1 on a 1-wide axis, else 2)
@@ -77,8 +78,7 @@ struct SmallArgs {
 template <int MODE, int NB>
 __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   constexpr int NW = 8, NG = MODE == 2 ? 4 : 1, D = 8, NQ = NG * NB;
-  static_assert(D % NG == 0, "a ring turn covers whole phase groups");
-  __shared__ __attribute__((aligned(16))) float part[NW * NQ * 256];   // [wave][q][pixel][channel]
+  __shared__ __attribute__((aligned(16))) float part[NW * NB * 256];   // [wave][block][pixel][channel]
   __shared__ __attribute__((aligned(16))) float val[NQ * 256];         // reduced tile [q][pixel][channel]
   __shared__ __attribute__((aligned(16))) float xh[NQ * 256];          // epi 2: normalised activations
   __shared__ float fin[2][16][16];                                     // per (local sample, channel)
@@ -101,85 +101,110 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
     ry[mb] = p >> a.lgw;
     rx[mb] = p & (w - 1);
   }
-  const int cbase = wave * a.U;
+  // K is cut over the waves by TAP: MODE 1 wave w takes taps w, w + 8, ...; MODE 2 wave w takes phase w & 3 and that
+  // phase's taps (w >> 2), (w >> 2) + 2.  Inside a tap the chunk loop only advances pointers.
+  const int g = MODE == 2 ? (wave & 3) : 0;
   const int ntaps = a.nty * a.ntx;
-  const int nunits = cbase < a.nchunk ? ntaps * a.U : 0;         // (tap, chunk) pairs of this wave; x NG steps each
+  const int tfirst = MODE == 2 ? (wave >> 2) : wave, tstep = MODE == 2 ? 2 : NW;
   const long wlane = (long)cl * 64 + kp * 16;                    // a lane's 16 bytes inside a [16 rows][32 k] slab
   const char* const wbase = a.w + (long)n0 * 64 + wlane;
   const bf16_t* const xlane = a.x + kp * 8;
+  const long wstep = MODE == 2 ? 16L * a.Cout * 64 : 4L * a.Cout * 64;      // bytes from chunk c to chunk c + 1
 
-  f32x4 acc[NG][NB];
+  f32x4 acc[NB];
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
+  for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
-    for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[g][mb][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[mb][j] = 0.f;
 
-  bf16x8 Wf[D], Xf[D][NB];
-  int ut = 0, uc = 0, uidx = 0;                                  // issue state: tap index, chunk index inside the wave's range
-  auto issue = [&](auto slotc) {
-    constexpr int slot = decltype(slotc)::value, g = slot % NG;
-    const bool live = uidx < nunits;
-    const int c = cbase + uc;
-    const char* wp = reinterpret_cast<const char*>(g_small_zero);
-    int ty = 0, tx = 0;                                          // tap coordinates
+  // issue state: the tap being streamed, the chunk inside it, the running pointers
+  int tcur = tfirst, ccur = 0;
+  const char* wp;
+  const bf16_t* xp[NB];
+  int xs[NB];
+  long ws;
+  auto open_tap = [&]() {
+    const bool live = tcur < ntaps;
+    const int q = tcur >> a.lgntx, rem = tcur & (a.ntx - 1);
+    int ty, tx;
+    wp = reinterpret_cast<const char*>(g_small_zero);
+    ws = 0;
     if (MODE == 1) {
-      const int q = ut >> a.lgntx;
-      ty = a.t0y + q; tx = a.t0x + (ut & (a.ntx - 1));
+      ty = a.t0y + q; tx = a.t0x + rem;
       const int rs = (ty & 1) * 2 + (tx & 1), ab = (ty >> 1) * 2 + (tx >> 1);
-      if (live) wp = wbase + ((long)(rs * a.nchunk + c) * 4 + ab) * a.Cout * 64;
+      if (live) { wp = wbase + ((long)rs * a.nchunk * 4 + ab) * a.Cout * 64; ws = wstep; }
     } else {
-      const int q = ut >> a.lgntx;
       ty = h == 1 ? (g >> 1) : q;
-      tx = w == 1 ? (g & 1) : (ut & (a.ntx - 1));
-      if (live) wp = wbase + (((long)c * 4 + ty * 2 + tx) * 4 + g) * a.Cout * 64;
+      tx = w == 1 ? (g & 1) : rem;
+      if (live) { wp = wbase + ((long)(ty * 2 + tx) * 4 + g) * a.Cout * 64; ws = wstep; }
     }
-    Wf[slot] = *reinterpret_cast<const bf16x8*>(wp);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
-      const bf16_t* xp = reinterpret_cast<const bf16_t*>(g_small_zero);
+      xp[mb] = reinterpret_cast<const bf16_t*>(g_small_zero);
+      xs[mb] = 0;
       if (MODE == 1) {
         const int iy = 2 * ry[mb] + ty - 1, ix = 2 * rx[mb] + tx - 1;
-        if (live && rok[mb] && (unsigned)iy < (unsigned)(2 * h) && (unsigned)ix < (unsigned)(2 * w))
-          xp = xlane + ((long)(rn[mb] * 2 * h + iy) * (2 * w) + ix) * a.ldx + c * 32;
+        if (live && rok[mb] && (unsigned)iy < (unsigned)(2 * h) && (unsigned)ix < (unsigned)(2 * w)) {
+          xp[mb] = xlane + ((long)(rn[mb] * 2 * h + iy) * (2 * w) + ix) * a.ldx;
+          xs[mb] = 32;
+        }
       } else {
         const int yy = ry[mb] + ty - (g >> 1), xx = rx[mb] + tx - (g & 1);
-        if (live && rok[mb] && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w)
-          xp = xlane + ((long)(rn[mb] * h + yy) * w + xx) * a.ldx + c * 32;
+        if (live && rok[mb] && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+          xp[mb] = xlane + ((long)(rn[mb] * h + yy) * w + xx) * a.ldx;
+          xs[mb] = 32;
+        }
       }
-      Xf[slot][mb] = *reinterpret_cast<const bf16x8*>(xp);
     }
-    if (g == NG - 1) {                                           // next (tap, chunk) unit: chunks fastest
-      ++uidx;
-      if (++uc == a.U) { uc = 0; ++ut; }
+  };
+  open_tap();
+
+  bf16x8 Wf[D], Xf[D][NB];
+  auto issue = [&](auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    Wf[slot] = *reinterpret_cast<const bf16x8*>(wp);
+    wp += ws;
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      Xf[slot][mb] = *reinterpret_cast<const bf16x8*>(xp[mb]);
+      xp[mb] += xs[mb];
+    }
+    if (++ccur == a.nchunk) {                                    // (wave-uniform) next tap of this wave
+      ccur = 0;
+      tcur += tstep;
+      open_tap();
     }
   };
 
+  int mytaps = 0;
+  for (int t = tfirst; t < ntaps; t += tstep) ++mytaps;
+  const int nsteps = mytaps * a.nchunk;
   sfor<D>([&](auto d) { issue(d); });
-  const int nsteps = nunits * NG;
   for (int base = 0; base < nsteps; base += D) {
     sfor<D>([&](auto d) {
-      constexpr int slot = decltype(d)::value, g = slot % NG;
+      constexpr int slot = decltype(d)::value;
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb)
-        acc[g][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot], Xf[slot][mb], acc[g][mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot], Xf[slot][mb], acc[mb], 0, 0, 0);
       issue(d);
     });
   }
 
-  // ---- the eight partial tiles meet in LDS ----
+  // ---- the partial tiles meet in LDS: [wave][block][pixel][channel] ----
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
-#pragma unroll
-    for (int mb = 0; mb < NB; ++mb)
-      *reinterpret_cast<f32x4*>(&part[((wave * NQ + g * NB + mb) * 16 + cl) * 16 + kp * 4]) = acc[g][mb];
+  for (int mb = 0; mb < NB; ++mb)
+    *reinterpret_cast<f32x4*>(&part[((wave * NB + mb) * 16 + cl) * 16 + kp * 4]) = acc[mb];
   __syncthreads();
   const bool normed = a.epi == 2 && n0 >= a.bwd_c0;
   for (int e = tid; e < NQ * 256; e += 512) {
     float s = 0.f;
+    if (MODE == 2) {                                             // group q / NB came from waves q / NB and q / NB + 4
+      const int gq = e / (NB * 256), r = e - gq * (NB * 256);
+      s = part[gq * NB * 256 + r] + part[(gq + 4) * NB * 256 + r];
+    } else {
 #pragma unroll
-    for (int wv = 0; wv < NW; ++wv) s += part[wv * NQ * 256 + e];
+      for (int wv = 0; wv < NW; ++wv) s += part[wv * NB * 256 + e];
+    }
     if (a.epi != 2 && a.bias) s += a.bias[n0 + (e & 15)];
     if (a.epi == 1) s = (float)(bf16_t)s;                        // the statistics are those of the values as stored
     val[e] = s;
@@ -336,9 +361,6 @@ inline bool small_plan(int mode, int B, int h, int w, int Cin, int Cout, SmallPl
   if (mode != 1 && mode != 2) return false;
   if (B <= 0 || !pow2(h) || !pow2(w) || Cin <= 0 || Cout <= 0 || (Cin % 32) || (Cout % 16)) return false;
   const int P = h * w;
-  const int nchunk = Cin / 32;
-  int U = nchunk / 8; if (U < 1) U = 1;
-  if (nchunk % U || nchunk / U > 8) return false;
   if (mode == 1) { if (P > 64) return false; }
   else if (P > 16) return false;                 // MODE 2: one 16-row block per phase (4 P output pixels <= 64 per sample)
   int SG, NB;
@@ -395,7 +417,7 @@ extern "C" int s2s_convsm_nhwc(int dtype, int mode, const void* x, int ldx, int 
   a.w = (const char*)w_packed; a.bias = bias;
   a.B = B; a.lgh = ilog2(h); a.lgw = ilog2(w); a.Cout = Cout;
   a.SG = pl.SG;
-  a.nchunk = Cin / 32; a.U = a.nchunk / 8 < 1 ? 1 : a.nchunk / 8;
+  a.nchunk = Cin / 32;
   if (mode == 1) {                                 // kernel rows that touch a real pixel for some output row
     a.t0y = h == 1 ? 1 : 0; a.nty = h == 1 ? 2 : 4;
     a.t0x = w == 1 ? 1 : 0; a.ntx = w == 1 ? 2 : 4;

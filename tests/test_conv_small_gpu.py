@@ -38,6 +38,18 @@ def _stats(z_nchw):
     return torch.stack([mu, inv, inv, -mu * inv]).contiguous().to(DEV)
 
 
+def _no_ties(z):
+    """Nudge the pixels whose normalised value is (nearly) zero: with four bf16 pixels per channel the mean often IS one of
+    them, and torch's relu'(0) = 0 against a rounded 1e-8 in the kernel is a knife edge, not a difference in arithmetic."""
+    for _ in range(8):
+        zn, _, _ = _inorm(z)
+        m = zn.abs() < 1e-3
+        if not bool(m.any()):
+            break
+        z = _rb(z + m.float() * 0.125)
+    return z
+
+
 def _pack(w, stride=2):
     from stain2stain_amd import ops
     return ops.pack_conv4x4_t(w.to(DEV), stride, torch.bfloat16)
@@ -99,7 +111,7 @@ def test_conv_data_gradient_ends_in_the_norm_backward(B, h, cin, cout, with_g2):
     """a = lrelu(IN(z)), r = relu(IN(z)); next = conv_s2(a): the launch takes d(next) and returns dz."""
     from stain2stain_amd import ops
     g = torch.Generator().manual_seed(B + h)
-    z = _rb(torch.randn(B, cin, 2 * h, 2 * h, generator=g)).requires_grad_(True)
+    z = _no_ties(_rb(torch.randn(B, cin, 2 * h, 2 * h, generator=g))).requires_grad_(True)
     w = _rb(torch.randn(cout, cin, 4, 4, generator=g) / (4.0 * cin ** 0.5))
     G = _rb(torch.randn(B, cout, h, h, generator=g))
     G2 = _rb(torch.randn(B, cin, 2 * h, 2 * h, generator=g)) if with_g2 else None
@@ -121,7 +133,8 @@ def test_transposed_data_gradient_splits_into_skip_and_norm_backward(B, h, C, co
     from stain2stain_amd import ops
     g = torch.Generator().manual_seed(B * 7 + h)
     skip = _rb(torch.randn(B, C, h, h, generator=g)).requires_grad_(True)
-    zu = _rb(torch.randn(B, C, h, h, generator=g)).requires_grad_(True)
+    zu = _rb(torch.randn(B, C, h, h, generator=g))
+    zu = (_no_ties(zu) if h > 1 else zu).requires_grad_(True)
     w = _rb(torch.randn(2 * C, cout, 4, 4, generator=g) / (2.0 * (2 * C) ** 0.5))
     G = _rb(torch.randn(B, cout, 2 * h, 2 * h, generator=g))
     if h > 1:
