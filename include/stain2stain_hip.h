@@ -349,7 +349,7 @@ int s2s_convt4x4s2_nhwc(int dtype, const void* x, int ldx, int Cin, const void* 
  * reduce, and InstanceNorm + activation (forward) or their backward (data gradient) are the epilogue.
  *   mode 1: nn.Conv2d(4, 2, 1) from the plain x [B][2h][2w][Cin] with wf -> [B][h][w][Cout], h * w <= 64;
  *   mode 2: nn.ConvTranspose2d(4, 2, 1) / the convolution's data gradient from x [B][h][w][Cin] with wd ->
- *           [B][2h][2w][Cout], h * w <= 16.   h, w powers of two, Cin % 32 == 0, Cout % 16 == 0; s2s_convsm_ok() != 0 says a shape is taken.
+ *           [B][2h][2w][Cout], h * w <= 16.   h, w powers of two, Cin % 64 == 0, Cout % 16 == 0; s2s_convsm_ok() != 0 says a shape is taken.
  *   epi 0: y = act ? lrelu(conv + bias, slope) : conv + bias; y2 (optional) = relu(y).
  *   epi 1: raw (optional) = bf16(conv + bias); stats[4][B][Cout] = mean, invstd, invstd, -mean * invstd of raw per
  *          (sample, channel) [InstanceNorm2d(affine=False, eps)]; y = lrelu(norm(raw), slope); y2 (optional) = relu(norm).

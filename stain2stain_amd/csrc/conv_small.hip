@@ -17,8 +17,8 @@
 // sub-pixel phase w & 3 and two of its four taps), so nothing is shared between waves until the end and the main loop
 // has no barrier and no LDS: per tap the im2col addresses are formed once and the chunk loop only advances pointers; a
 // wave streams its weight fragments (16 output channels x 32 k = 1 KiB contiguous in the packed operand) and its pixel
-// fragments (16 pixel rows x 64 B) straight into registers through an 8-deep ring of plain global loads, one
-// v_mfma_f32_16x16x32_bf16 per (weight fragment, pixel block).  Operand order as everywhere
+// fragments (16 pixel rows x 64 B) straight into registers through a 4-deep ring of plain global loads (a ring slot =
+// two chunks = one 128-byte line per pixel row), one v_mfma_f32_16x16x32_bf16 per (weight fragment, pixel block).  Operand order as everywhere
 // (weights as A, pixels as B): a lane's four accumulator registers are four consecutive channels of one pixel.  The
 // eight partial tiles meet in LDS once.
 //
@@ -57,6 +57,7 @@ struct SmallArgs {
   int Cout;                   // output channels of the launch (gridDim.y * 16)
   int SG;                     // samples per workgroup (SG * rows per sample <= 16 * NB)
   int nchunk;                 // Cin / 32
+  int nx, ny;                 // tiles: sample groups x 16-channel tiles (the grid is their product, see the kernel)
   int lgntx;
   int t0y, nty, t0x, ntx;     // live taps: MODE 1 kernel rows t0y .. t0y + nty - 1 (of 4), columns likewise;
                               // MODE 2: nty / ntx = live taps per phase and axis (1 on a 1-wide axis, else 2)
@@ -77,7 +78,7 @@ struct SmallArgs {
 // (the sub-pixel phases), MODE 1 one.
 template <int MODE, int NB>
 __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
-  constexpr int NW = 8, NG = MODE == 2 ? 4 : 1, D = 8, NQ = NG * NB;
+  constexpr int NW = 8, NG = MODE == 2 ? 4 : 1, D = 4, NQ = NG * NB;
   __shared__ __attribute__((aligned(16))) float part[NW * NB * 256];   // [wave][block][pixel][channel]
   __shared__ __attribute__((aligned(16))) float val[NQ * 256];         // reduced tile [q][pixel][channel]
   __shared__ __attribute__((aligned(16))) float xh[NQ * 256];          // epi 2: normalised activations
@@ -86,8 +87,24 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cl = lane & 15, kp = lane >> 4;
-  const int n0 = blockIdx.y * 16;
-  const int s0 = blockIdx.x * a.SG;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.  With
+  // the plain (sample group, channel tile) order every XCD streamed the layer's WHOLE weight operand (8-17 MB through a
+  // 4 MB L2, eight times over from the Infinity Cache: the launches ran at its ~9 TB/s whatever the loop did); here an
+  // XCD owns ny / 8 channel tiles for all sample groups, so it streams an eighth of the weights and re-reads them from
+  // its own L2.
+  int bx, by;
+  {
+    const int L = blockIdx.x;
+    if ((a.ny & 7) == 0) {
+      const int per = a.ny >> 3, j = L >> 3;
+      by = (L & 7) * per + j % per;
+      bx = j / per;
+    } else {
+      bx = L % a.nx; by = L / a.nx;
+    }
+  }
+  const int n0 = by * 16;
+  const int s0 = bx * a.SG;
   const int h = 1 << a.lgh, w = 1 << a.lgw, lgP = a.lgh + a.lgw, P = 1 << lgP;
 
   // this lane's pixel rows: R = mb * 16 + cl -> local sample R >> lgP, pixel R & (P - 1)
@@ -106,10 +123,18 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   const int g = MODE == 2 ? (wave & 3) : 0;
   const int ntaps = a.nty * a.ntx;
   const int tfirst = MODE == 2 ? (wave >> 2) : wave, tstep = MODE == 2 ? 2 : NW;
-  const long wlane = (long)cl * 64 + kp * 16;                    // a lane's 16 bytes inside a [16 rows][32 k] slab
+  // A step is a PAIR of 32-channel chunks = 128 B of every pixel row, and the k index of the two MFMAs is permuted so
+  // that lane group kp owns 32 contiguous bytes of it (channels 64 p + 16 kp + [0, 8) for the first MFMA, + [8, 16) for
+  // the second): the four lane groups of a row read one whole 128-byte line with two back-to-back 16-byte loads.  (With
+  // one chunk per step every load used half a line and the launch ran at the L2's line rate for half the bytes.)  The
+  // weight fragments follow the same permutation: lane group kp reads row cl of slab 2 p + (kp >> 1), bytes
+  // 32 (kp & 1) + [0, 16) and + [16, 32).
+  const long wchunk = MODE == 2 ? 16L * a.Cout * 64 : 4L * a.Cout * 64;     // bytes from chunk c to chunk c + 1
+  const long wlane = (long)(kp >> 1) * wchunk + (long)cl * 64 + (kp & 1) * 32;
   const char* const wbase = a.w + (long)n0 * 64 + wlane;
-  const bf16_t* const xlane = a.x + kp * 8;
-  const long wstep = MODE == 2 ? 16L * a.Cout * 64 : 4L * a.Cout * 64;      // bytes from chunk c to chunk c + 1
+  const bf16_t* const xlane = a.x + kp * 16;
+  const long wstep = 2 * wchunk;
+  const int npair = a.nchunk >> 1;
 
   f32x4 acc[NB];
 #pragma unroll
@@ -146,30 +171,32 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
         const int iy = 2 * ry[mb] + ty - 1, ix = 2 * rx[mb] + tx - 1;
         if (live && rok[mb] && (unsigned)iy < (unsigned)(2 * h) && (unsigned)ix < (unsigned)(2 * w)) {
           xp[mb] = xlane + ((long)(rn[mb] * 2 * h + iy) * (2 * w) + ix) * a.ldx;
-          xs[mb] = 32;
+          xs[mb] = 64;
         }
       } else {
         const int yy = ry[mb] + ty - (g >> 1), xx = rx[mb] + tx - (g & 1);
         if (live && rok[mb] && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
           xp[mb] = xlane + ((long)(rn[mb] * h + yy) * w + xx) * a.ldx;
-          xs[mb] = 32;
+          xs[mb] = 64;
         }
       }
     }
   };
   open_tap();
 
-  bf16x8 Wf[D], Xf[D][NB];
+  bf16x8 Wf[D][2], Xf[D][NB][2];
   auto issue = [&](auto slotc) {
     constexpr int slot = decltype(slotc)::value;
-    Wf[slot] = *reinterpret_cast<const bf16x8*>(wp);
+    Wf[slot][0] = *reinterpret_cast<const bf16x8*>(wp);
+    Wf[slot][1] = *reinterpret_cast<const bf16x8*>(wp + 16);
     wp += ws;
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
-      Xf[slot][mb] = *reinterpret_cast<const bf16x8*>(xp[mb]);
+      Xf[slot][mb][0] = *reinterpret_cast<const bf16x8*>(xp[mb]);
+      Xf[slot][mb][1] = *reinterpret_cast<const bf16x8*>(xp[mb] + 8);
       xp[mb] += xs[mb];
     }
-    if (++ccur == a.nchunk) {                                    // (wave-uniform) next tap of this wave
+    if (++ccur == npair) {                                       // (wave-uniform) next tap of this wave
       ccur = 0;
       tcur += tstep;
       open_tap();
@@ -178,14 +205,16 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
 
   int mytaps = 0;
   for (int t = tfirst; t < ntaps; t += tstep) ++mytaps;
-  const int nsteps = mytaps * a.nchunk;
+  const int nsteps = mytaps * npair;
   sfor<D>([&](auto d) { issue(d); });
   for (int base = 0; base < nsteps; base += D) {
     sfor<D>([&](auto d) {
       constexpr int slot = decltype(d)::value;
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb)
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot], Xf[slot][mb], acc[mb], 0, 0, 0);
+      for (int mb = 0; mb < NB; ++mb) {
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot][0], Xf[slot][mb][0], acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot][1], Xf[slot][mb][1], acc[mb], 0, 0, 0);
+      }
       issue(d);
     });
   }
@@ -359,7 +388,7 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 struct SmallPlan { int P, SG, NB; };
 inline bool small_plan(int mode, int B, int h, int w, int Cin, int Cout, SmallPlan* pl) {
   if (mode != 1 && mode != 2) return false;
-  if (B <= 0 || !pow2(h) || !pow2(w) || Cin <= 0 || Cout <= 0 || (Cin % 32) || (Cout % 16)) return false;
+  if (B <= 0 || !pow2(h) || !pow2(w) || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 16)) return false;
   const int P = h * w;
   if (mode == 1) { if (P > 64) return false; }
   else if (P > 16) return false;                 // MODE 2: one 16-row block per phase (4 P output pixels <= 64 per sample)
@@ -375,7 +404,7 @@ inline bool small_plan(int mode, int B, int h, int w, int Cin, int Cout, SmallPl
 
 // 1 when (mode, shape) is one of the sample-complete launches below: h x w a power-of-two map (mode 1: the OUTPUT map of
 // the stride-2 convolution, at most 64 pixels; mode 2: the INPUT map of the transposed form, at most 16 pixels),
-// Cin % 32 == 0, Cout % 16 == 0, bf16.
+// Cin % 64 == 0, Cout % 16 == 0, bf16.
 extern "C" int s2s_convsm_ok(int dtype, int mode, int B, int h, int w, int Cin, int Cout) {
   SmallPlan pl;
   return dtype == S2S_BF16 && small_plan(mode, B, h, w, Cin, Cout, &pl) ? 1 : 0;
@@ -430,7 +459,8 @@ extern "C" int s2s_convsm_nhwc(int dtype, int mode, const void* x, int ldx, int 
   a.raw = (bf16_t*)raw; a.ldraw = ldraw; a.y = (bf16_t*)y; a.ldy = ldy; a.y2 = (bf16_t*)y2; a.ldy2 = ldy2;
   a.stats = stats; a.stats_in = stats_in; a.z = (const bf16_t*)z; a.ldz = ldz; a.g2 = (const bf16_t*)g2; a.ldg2 = ldg2;
   a.bwd_c0 = bwd_c0;
-  const dim3 grid(cdiv(B, pl.SG), Cout / 16);
+  a.nx = cdiv(B, pl.SG); a.ny = Cout / 16;
+  const dim3 grid(a.nx * a.ny);
   hipStream_t s = (hipStream_t)stream;
   if (mode == 2) hipLaunchKernelGGL((convsm_kernel<2, 1>), grid, dim3(512), 0, s, a);
   else if (pl.NB == 1) hipLaunchKernelGGL((convsm_kernel<1, 1>), grid, dim3(512), 0, s, a);

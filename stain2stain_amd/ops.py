@@ -1440,3 +1440,15 @@ def convsm_bwd(mode: int, g: torch.Tensor, w_packed: torch.Tensor, cout: int, *,
                               ppl, ldpl, 0, ps, pz, ldz, p2, ld2, int(bwd_c0), B, h, w, cout, _stream())
     _native.check(rc, "convsm_bwd")
     return dz, plain
+
+
+def convsm_wins(dtype: torch.dtype, mode: int, B: int, h: int, w: int, cin: int, cout: int) -> bool:
+    """Launch policy of the inner levels: where the sample-complete launch measured faster than split-K convolution +
+    single-launch InstanceNorm at batch 16 (scripts/p2p_small_bench.py, rocprofv3 kernel times).  The launch streams the
+    im2col'd pixels from L2 per workgroup, so it wins on the maps of at most 4x4 (mode 1 with <= 512 output channels) /
+    2x2 (mode 1 with more, mode 2) and loses above."""
+    if not convsm_ok(dtype, mode, B, h, w, cin, cout):
+        return False
+    if mode == 1:
+        return h * w <= 4 or (h * w <= 16 and cout <= 512)
+    return h * w <= 4

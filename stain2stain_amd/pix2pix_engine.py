@@ -185,6 +185,10 @@ class _Packer:
 # ----------------------------------------------------------------------------------------------------------------------
 # layer forward / backward on the kernels
 # ----------------------------------------------------------------------------------------------------------------------
+def _b(l: "_Layer"):
+    return None if l.bias is None else l.bias.detach()
+
+
 def _conv_s2_fwd(l: _Layer, x: torch.Tensor, act: bool = False, slope: float = 0.0, out2=None, defer: bool = False):
     """nn.Conv2d(k=4, s=2, p=1) of the plain NHWC tensor x.  Returns (y, saved): ``saved`` is what the weight gradient
     reads -- x itself on the layout-free bf16 kernels (the loader does the space-to-depth in its addresses), else the
@@ -341,12 +345,21 @@ class Pix2PixTrainer:
         x = ops.p2p_pack_input(src, None, torch.empty((B, H, W, 8), dtype=dt, device=dev))
         for i, l in enumerate(self.g_down):
             skip = ctx.cat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
+            small = i > 0 and ops.convsm_wins(dt, 1, B, x.shape[1] // 2, x.shape[2] // 2, x.shape[3], l.conv_out)
             if i == 0:                                    # LeakyReLU, no norm
                 a, saved = _conv_s2_fwd(l, x, act=True, slope=LRELU, out2=skip)
                 ctx.raw.append(None); ctx.stats.append(None)
             elif i == n - 1:                              # innermost: ReLU, no norm
-                a, saved = _conv_s2_fwd(l, x, act=True, slope=0.0)
+                if small:                                 # (one sample-complete launch, dead taps skipped)
+                    a, saved = ops.convsm_fwd(1, x, l.wf, _b(l), l.conv_out, norm=False, act=True, slope=0.0)[0], x
+                else:
+                    a, saved = _conv_s2_fwd(l, x, act=True, slope=0.0)
                 ctx.raw.append(None); ctx.stats.append(None)
+            elif small:                                   # inner level: convolution + norm + both outputs in one launch
+                a, raw, st = ops.convsm_fwd(1, x, l.wf, _b(l), l.conv_out, norm=True, slope=LRELU, out2=skip)
+                saved = x
+                ctx.stats.append(st)
+                ctx.raw.append(raw)
             else:
                 raw, saved = _conv_s2_fwd(l, x, defer=FOLD_IN_NORM)
                 if isinstance(raw, ops.SplitSum):        # inner level: the norm folds the split-K slabs itself
@@ -362,6 +375,12 @@ class Pix2PixTrainer:
             x = a
         for j, l in enumerate(self.g_up):
             xin = x if j == 0 else ctx.cat[j]
+            if j < n - 1 and ops.convsm_wins(dt, 2, B, xin.shape[1], xin.shape[2], xin.shape[3], l.conv_out):
+                C = l.conv_out                            # transposed convolution + norm + ReLU into the concat buffer
+                _, hraw, st = ops.convsm_fwd(2, xin, l.wd, _b(l), C, norm=True, slope=0.0, out=ctx.cat[j + 1][..., C:])
+                ctx.ustats.append(st)
+                ctx.uraw.append(hraw)
+                continue
             hraw = _conv_t2_fwd(l, xin, defer=FOLD_IN_NORM and j < n - 1)
             if j < n - 1:
                 C = l.conv_out
@@ -397,36 +416,65 @@ class Pix2PixTrainer:
         ch = [l.conv_out for l in self.g_down]
         grp = 0
         g = dh
-        dcat = [None] * n
+        B, dt = dh.shape[0], dh.dtype
+        upg = [None] * n           # gradient wrt up layer j's OUTPUT ahead of its norm backward (the second half of cat[j + 1])
+        skipg = [None] * n         # gradient wrt the skip half of cat[j] (second gradient of down layer n - 1 - j's norm)
+        g_is_dz = False            # g already went through the norm backward of the layer it now belongs to
         for j in range(n - 1, -1, -1):
             l = self.g_up[j]
             if j == n - 1:
                 if l.bias is not None:
                     ops.channel_sum_into(g, gr[l.name + ".bias"])
-            else:
-                C = l.conv_out
-                g = ops.instnorm_lrelu_bwd2(dcat[j + 1][..., C:], None, ctx.uraw[j], ctx.ustats[j], 0.0)
+            elif not g_is_dz:
+                g = ops.instnorm_lrelu_bwd2(upg[j], None, ctx.uraw[j], ctx.ustats[j], 0.0)
+            g_is_dz = False
             xin = ctx.act[n - 1] if j == 0 else ctx.cat[j]
-            dx = _conv_t2_bwd(l, g, xin, gr[l.name + ".weight"])
-            if j == 0:
-                g = dx
+            gw = gr[l.name + ".weight"]
+            # data gradient = the stride-2 convolution of g with the forward operand; on the inner levels one launch that
+            # ends in the norm backward of up layer j - 1 (whose output is the second half of this layer's input)
+            hin, win = xin.shape[1], xin.shape[2]
+            if ops.convsm_wins(dt, 1, B, hin, win, g.shape[3], l.conv_in):
+                engine.run_on_side(lambda x=xin, gg=g, gw=gw: ops.convkxk_wgrad(x, gg, gw, 2, x_plain=True), (g,))
+                if j == 0:
+                    _, g = ops.convsm_bwd(1, g, l.wf, l.conv_in, z=None, stats=None, g2=None, slope=0.0, bwd_c0=l.conv_in)
+                else:
+                    Cs = l.conv_in // 2
+                    g, skipg[j] = ops.convsm_bwd(1, g, l.wf, l.conv_in, z=ctx.uraw[j - 1], stats=ctx.ustats[j - 1], g2=None,
+                                                 slope=0.0, bwd_c0=Cs)
+                    g_is_dz = True
             else:
-                dcat[j] = dx
+                dx = _conv_t2_bwd(l, g, xin, gw)
+                if j == 0:
+                    g = dx
+                else:
+                    Cs = l.conv_in // 2
+                    skipg[j], upg[j - 1] = dx[..., :Cs], dx[..., Cs:]
             self._mark(self.pG, grp)
             if update:
                 self._update_group(grp, l, hyper_dev)
             grp += 1
+        g_is_dz = False
         for i in range(n - 1, -1, -1):
             l = self.g_down[i]
-            skip_g = dcat[n - 1 - i][..., :ch[i]] if i < n - 1 else None
-            if i == n - 1:
+            skip_g = skipg[n - 1 - i] if i < n - 1 else None
+            if g_is_dz:
+                pass
+            elif i == n - 1:
                 g = ops.p2p_act_bwd(g, None, ctx.act[i], 0.0, gr.get(l.name + ".bias"))
             elif i == 0:
                 g = ops.p2p_act_bwd(g, skip_g, ctx.act[0], LRELU, gr.get(l.name + ".bias"))
             else:
                 g = ops.instnorm_lrelu_bwd2(g, skip_g, ctx.raw[i], ctx.stats[i], LRELU)
-            g = _conv_s2_bwd(l, g, ctx.xs[i], gr[l.name + ".weight"], need_dx=(i > 0),
-                             defer=FOLD_IN_NORM and i > 1)           # (layer i-1 has a norm)
+            g_is_dz = False
+            gw = gr[l.name + ".weight"]
+            # (layer i - 1 has a norm for i >= 2: the inner levels' data gradient ends in it)
+            if i >= 2 and ops.convsm_wins(dt, 2, B, g.shape[1], g.shape[2], g.shape[3], l.conv_in):
+                engine.run_on_side(lambda gg=g, x=ctx.xs[i], gw=gw: ops.convkxk_wgrad(gg, x, gw, 2, x_plain=True), (g,))
+                g, _ = ops.convsm_bwd(2, g, l.wd, l.conv_in, z=ctx.raw[i - 1], stats=ctx.stats[i - 1],
+                                      g2=skipg[n - i], slope=LRELU)
+                g_is_dz = True
+            else:
+                g = _conv_s2_bwd(l, g, ctx.xs[i], gw, need_dx=(i > 0), defer=FOLD_IN_NORM and i > 1)
             self._mark(self.pG, grp)
             if update:
                 self._update_group(grp, l, hyper_dev)
