@@ -200,6 +200,56 @@ def fp32_parity_leg(dev, B: int) -> dict:
                     "headline is held to 4e-3 per op against torch fp32 on bf16-rounded operands"}
 
 
+def dropin_leg(dev, B: int, steps: int, fused_ms: float) -> dict:
+    """The path a user of the reference gets after the ``_target_`` swap: ``FlowUNet`` under autograd inside
+    ``ConditionalFlowMatchingModule`` driven the way Lightning's automatic optimisation drives the reference's
+    LightningModule (src/models/conditional_flow_matching.py:76-88 ``training_step``, :112-131 ``configure_optimizers``):
+    ``optimizer.zero_grad(); loss = module.training_step(batch, i); loss.backward(); optimizer.step()`` -- same network,
+    batch, precision and timing contract as the headline, which runs the fused trainer instead.  Timed with the optimiser
+    the reference's config names (``torch.optim.Adam(lr=1e-4, weight_decay=1e-5)``) and with ``stain2stain_amd.FusedAdam``
+    (the same update as one HIP launch, selected by the same ``_target_`` mechanism)."""
+    from functools import partial
+    from stain2stain_amd import ConditionalFlowMatchingModule, FlowUNet, FusedAdam
+    out = {"metric": f"paired {TILE}x{TILE} stain tiles/sec (drop-in modules under autograd: zero_grad, training_step, "
+                     "backward, optimizer.step)", "unit": "tiles/s", "dtype": "bf16", "steps": steps}
+    g = torch.Generator().manual_seed(1984)
+    pool = [((torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev), (torch.rand(B, 3, TILE, TILE, generator=g) * 2 - 1).to(dev))
+            for _ in range(4)]
+    for name, opt_cls in (("fused_adam", FusedAdam), ("torch_adam", torch.optim.Adam)):
+        torch.manual_seed(1984)
+        net = FlowUNet(3, FEATURES, 3, 256).to(dev).train()
+        mod = ConditionalFlowMatchingModule(net, optimizer=partial(opt_cls, lr=1e-4, weight_decay=1e-5))
+        opt = mod.configure_optimizers()["optimizer"]
+
+        def one(i):
+            opt.zero_grad()
+            loss = mod.training_step(pool[i % 4], i)
+            loss.backward()
+            opt.step()
+            return loss
+
+        for i in range(3):
+            one(i)
+        pause = _GcPause()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = one(3 + i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        pause.resume()
+        out[name] = {"ms_per_step": round(ms, 3), "tiles_per_s": round(B * 1e3 / ms, 2), "final_loss": round(float(loss), 6)}
+        del net, mod, opt
+        torch.cuda.empty_cache()
+    out["value"] = out["fused_adam"]["tiles_per_s"]
+    out["ms_per_step"] = out["fused_adam"]["ms_per_step"]
+    out["vs_fused_trainer"] = round(out["ms_per_step"] / fused_ms, 4)
+    out["config"] = {"workload": f"CFM U-Net {FEATURES} 3x{TILE}x{TILE}, batch {B}, stain2stain_amd.FlowUNet inside "
+                                 "ConditionalFlowMatchingModule; optimizer = stain2stain_amd.FusedAdam(lr 1e-4, wd 1e-5) "
+                                 "(torch_adam: torch.optim.Adam, the class the reference's config names)"}
+    return out
+
+
 class _GcPause:
     """No cyclic garbage collection inside a timed region.  A full (generation 2) collection walks every object torch
     has created -- 60-80 ms here -- and when it fires is a matter of allocation counts: with the package loaded from its
@@ -597,6 +647,8 @@ def main() -> None:
         extras["sample"] = sample_leg(dev)
         torch.cuda.empty_cache()
         extras["fp32_parity"] = fp32_parity_leg(dev, B)
+        torch.cuda.empty_cache()
+        extras["dropin"] = dropin_leg(dev, B, max(5, args.steps // 2), out["ms_per_step"])
         torch.cuda.empty_cache()
     if not args.no_pix2pix and default_line:
         del trainer, net

@@ -196,6 +196,12 @@ int s2s_adam_step(float* p, const float* g, float* m, float* v, long n, int step
  * sqrt(1 - beta2^step), grad_scale}: the launch a hipGraph-captured training step replays while the host refreshes the
  * eight floats (Lightning's optimizer.step() / scheduler surface, conditional_flow_matching.py:112-131) */
 int s2s_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, void* stream);
+/* The same step over a list of tensors in one launch (ordinary module parameters + the gradients autograd left in .grad:
+ * stain2stain_amd.FusedAdam, the optimiser of the drop-in path): desc = device long[ntensors][6] {p, g, m, v, n, first
+ * block}; a tensor occupies s2s_adam_multi_blocks(n) blocks, total = their sum. */
+long s2s_adam_multi_blocks(long n);
+int s2s_adam_multi(const void* desc, int ntensors, long total, int step, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, void* stream);
 long s2s_pack_conv3x3_fwd_elems(int Cout, int Cin);
 long s2s_pack_conv3x3_dgrad_elems(int Cout, int Cin);
 int s2s_pack_conv3x3(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, void* stream);

@@ -84,6 +84,24 @@ def _fresh_grads(named: Sequence[Tuple[str, torch.Tensor]]) -> Dict[str, torch.T
     return {n: torch.empty_like(p, dtype=torch.float32) for n, p in named}
 
 
+class _side_wgrads:
+    """Inside a module's autograd backward: the conv weight gradients go to a second HIP stream (engine.run_on_side), where
+    they run beside the bandwidth-bound BatchNorm / up-sampling backward passes as in the fused trainer, and the compute
+    stream joins it before the gradients are handed back to autograd."""
+
+    def __init__(self, device):
+        self.side = ops.shared_side_stream(device)
+
+    def __enter__(self):
+        self.prev, engine.side_stream = engine.side_stream, self.side
+        return self
+
+    def __exit__(self, *exc):
+        engine.side_stream = self.prev
+        engine.join_side(self.side)
+        return False
+
+
 # ------------------------------------------------------------------------------------------------
 class TimeEmbedding(nn.Module):
     """Sinusoidal embedding of the raw flow time t in [0, 1] (no parameters)."""
@@ -114,7 +132,8 @@ class _EncoderFn(torch.autograd.Function):
         named = list(mod.named_parameters())
         grads = _fresh_grads(named)
         df = [None if g is None else _as_nhwc(g, ectx.dtype) for g in dfeats]
-        engine.encoder_backward(mod._blocks, ectx, df, grads)
+        with _side_wgrads(ectx.x_nchw.device):
+            engine.encoder_backward(mod._blocks, ectx, df, grads)
         ctx.ectx = None
         return (None, None) + tuple(grads[n] for n, _ in named)
 
@@ -176,8 +195,9 @@ class _DecoderFn(torch.autograd.Function):
             raise RuntimeError("stain2stain_amd: backward through an eval-mode forward is not supported")
         named = list(mod.named_parameters())
         grads = _fresh_grads(named)
-        dbott, dskips, dtemb = engine.decoder_backward(mod, dctx, dv.contiguous().float(), grads,
-                                                       need_dt_emb=ctx.need_temb)
+        with _side_wgrads(dv.device):
+            dbott, dskips, dtemb = engine.decoder_backward(mod, dctx, dv.contiguous().float(), grads,
+                                                           need_dt_emb=ctx.need_temb)
         ctx.dctx = None
         outs = (None, None, dbott.permute(0, 3, 1, 2), dtemb) + tuple(d.permute(0, 3, 1, 2) for d in dskips)
         return outs + tuple(grads[n] for n, _ in named)
@@ -236,7 +256,8 @@ class _SegDecoderFn(torch.autograd.Function):
             raise RuntimeError("stain2stain_amd: backward through an eval-mode forward is not supported")
         named = list(mod.named_parameters())
         grads = _fresh_grads(named)
-        dbott, dskips, _ = engine.decoder_backward(mod, dctx, dv.contiguous().float(), grads)
+        with _side_wgrads(dv.device):
+            dbott, dskips, _ = engine.decoder_backward(mod, dctx, dv.contiguous().float(), grads)
         ctx.dctx = None
         outs = (None, None, dbott.permute(0, 3, 1, 2)) + tuple(d.permute(0, 3, 1, 2) for d in dskips)
         return outs + tuple(grads[n] for n, _ in named)

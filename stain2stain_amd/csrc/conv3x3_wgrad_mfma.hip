@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void conv2x2_wgrad_flat_kernel(WgradArgs a)
 // pairs: its 64 virtual input channels are the four (r, s) sub-pixel groups of SIXTEEN real channels (the flat kernel
 // takes 64 consecutive virtual channels = one (r, s) of 64 real ones, a quarter of every 64-byte [4][4] block), and the
 // 64 x 16 x 16 tile leaves through LDS as 64 rows of 1 KiB.  Double-buffered over the (at most eight) pixel tiles.
-__global__ __launch_bounds__(256, 1) void conv2x2_wgrad_small_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
+__global__ __launch_bounds__(256, 2) void conv2x2_wgrad_small_kernel(WgradArgs a, float* __restrict__ grad, int accumulate) {
   using T = bf16_t;
   constexpr int NT = 4, NPX = 128;
   constexpr int DY_BYTES = 2 * NPX * 64, PLANE = NPX * 64, X_BYTES = 2 * NT * PLANE, BUF = DY_BYTES + X_BYTES;
@@ -1653,10 +1653,11 @@ extern "C" int s2s_convkxk_wgrad_nhwc(int dtype, const void* dy, int lddy, int C
       if (layout == 1 && a.ntiles <= 8 && ((cin / 4) % 16) == 0) {
         // at most 1024 pixels in the whole batch: one workgroup per (64 o, 16 c) block reduces all of them and writes the
         // [Cout][C][4][4] gradient itself -- no slabs, no fold launch
-        constexpr int lds_small = 2 * (2 * 128 * 64 + 2 * 4 * 128 * 64);
+        constexpr int lds_buf = 2 * 128 * 64 + 2 * 4 * 128 * 64;
         static unsigned long long attr_small = 0;   // hipFuncSetAttribute is per device
-        if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(conv2x2_wgrad_small_kernel), lds_small, &attr_small)) return rc2;
-        hipLaunchKernelGGL(conv2x2_wgrad_small_kernel, dim3(cin / 64, cdiv(Cout, 64)), dim3(256), lds_small, s, a, grad, accumulate);
+        if (int rc2 = s2s_allow_dyn_lds(reinterpret_cast<const void*>(conv2x2_wgrad_small_kernel), 2 * lds_buf, &attr_small)) return rc2;
+        // (a single pixel tile needs one buffer: 80 KiB, so two workgroups share a CU and one's stores run under the other's loads)
+        hipLaunchKernelGGL(conv2x2_wgrad_small_kernel, dim3(cin / 64, cdiv(Cout, 64)), dim3(256), (a.ntiles == 1 ? 1 : 2) * lds_buf, s, a, grad, accumulate);
         S2S_LAUNCH_CHECK();
         return S2S_OK;
       }

@@ -43,6 +43,46 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
   adam_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]);
 }
 
+// The same step over a LIST of tensors in one launch (the drop-in path: ordinary module parameters with the gradients
+// autograd left in ``.grad``, stain2stain_amd.FusedAdam): desc[t] = {p, g, m, v, n, first block}; a block owns 4096
+// consecutive elements of one tensor.  Element for element the arithmetic of adam_body.
+struct AdamDesc {
+  long p, g, m, v, n, start;
+};
+constexpr int ADAM_MULTI_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamDesc* __restrict__ desc, int nt, float lr, float beta1,
+                                                         float beta2, float eps, float weight_decay, float bc1,
+                                                         float bc2_sqrt, float grad_scale) {
+  int lo = 0, hi = nt - 1;                       // last tensor whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].start <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamDesc d = desc[lo];
+  float* __restrict__ p = reinterpret_cast<float*>(d.p);
+  const float* __restrict__ g = reinterpret_cast<const float*>(d.g);
+  float* __restrict__ m = reinterpret_cast<float*>(d.m);
+  float* __restrict__ v = reinterpret_cast<float*>(d.v);
+  const long base = ((long)blockIdx.x - d.start) * ADAM_MULTI_CHUNK;
+  const float step_size = lr / bc1;
+#pragma unroll 4
+  for (int k = 0; k < ADAM_MULTI_CHUNK / 256; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i < d.n) {
+      const float pi = p[i];
+      float gi = g[i] * grad_scale;
+      if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
+      const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+      const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      p[i] = pi - step_size * (mi / denom);
+      m[i] = mi;
+      v[i] = vi;
+    }
+  }
+}
+
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout,
                                     int Cin) {
@@ -178,6 +218,23 @@ extern "C" int s2s_adam_step(float* p, const float* g, float* m, float* v, long 
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
+// blocks one tensor of n elements occupies in s2s_adam_multi (the caller accumulates them into desc[t][5])
+extern "C" long s2s_adam_multi_blocks(long n) { return n <= 0 ? S2S_ERR_SHAPE : (n + ADAM_MULTI_CHUNK - 1) / ADAM_MULTI_CHUNK; }
+
+// desc: device long[ntensors][6] = {p, g, m, v (fp32 device pointers), n, first block}; total = all blocks
+extern "C" int s2s_adam_multi(const void* desc, int ntensors, long total, int step, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float grad_scale, void* stream) {
+  if (!desc) return S2S_ERR_NULL;
+  if (ntensors <= 0 || total <= 0 || total >= (1L << 31) || step <= 0) return S2S_ERR_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const AdamDesc*>(desc), ntensors, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }

@@ -175,6 +175,19 @@ def side_stream_for(device) -> Optional[torch.cuda.Stream]:
     return torch.cuda.Stream(device=device)
 
 
+_SHARED_SIDE = {}
+
+
+def shared_side_stream(device) -> Optional[torch.cuda.Stream]:
+    """One weight-gradient stream per device for the autograd Functions of the drop-in modules (the fused trainers own
+    theirs): created once, None with S2S_WGRAD_STREAM=0."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SHARED_SIDE:
+        _SHARED_SIDE[key] = side_stream_for(dev)
+    return _SHARED_SIDE[key]
+
+
 class TimingEvent:
     """A HIP event that only carries a timestamp (``s2s_event_create(timing_only=1)``: no system-scope fence when it
     completes), with the two methods of ``torch.cuda.Event`` the brackets use.  S2S_TIMING_EVENTS=0: torch's events."""
