@@ -71,13 +71,19 @@ def test_dropin_training_step_with_fused_adam_tracks_the_fused_trainer():
     opt = FusedAdam(list(na.parameters()), lr=1e-3, weight_decay=1e-5)
     fm = ConditionalFlowMatcher(0.0)
     tr = CFMTrainer(nb, lr=1e-3, weight_decay=1e-5)
-    for t in ts:
+    for s, t in enumerate(ts):
         opt.zero_grad()
         _, xt, ut = fm.sample_location_and_conditional_flow(x0, x1, t)
         loss = torch.mean((na(t, xt) - ut) ** 2)
         loss.backward()
+        lb, _ = tr.forward_backward(x0, x1, t)
+        assert abs(float(loss) - float(lb)) < (1e-5 if s == 0 else 2e-3) * abs(float(lb))
+        if s == 0:      # identical parameters: the two backward passes agree to rounding (head + loss are fused in one only)
+            for (k, a), (_, b) in zip(na.named_parameters(), nb.named_parameters()):
+                scale = float(b.grad.abs().max())
+                assert float((a.grad - b.grad).abs().max()) <= 1e-4 * scale + 1e-9, k
         opt.step()
-        lb = tr.step(x0, x1, t)
-        assert abs(float(loss) - float(lb)) < 1e-5 * abs(float(lb))
+        tr.optimizer_step()
+    # (after Adam, elements whose gradient is rounding noise move by +-lr in either run: compare the bulk)
     for (k, a), (_, b) in zip(na.named_parameters(), nb.named_parameters()):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, k
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6, k
