@@ -179,6 +179,8 @@ def repack_stale(cbs: Sequence[ConvBN], dtype: torch.dtype) -> None:
     stale = []
     for cb in cbs:
         w = cb.conv.weight
+        if not w.is_cuda:              # (a CPU module: the first op raises "no CPU path")
+            return
         if cb._pack_key.get(dtype) != (w.data_ptr(), w._version, w.device):
             stale.append(cb)
     if len(stale) < 2:

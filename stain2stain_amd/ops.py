@@ -833,6 +833,8 @@ def pack_conv3x3(w_oihw: torch.Tensor, dtype: torch.dtype, want_dgrad: bool = Tr
 def pack_conv3x3_batched(desc: torch.Tensor, total: int, dtype: torch.dtype) -> None:
     """desc: int64 [nlayers, 6] device tensor {w ptr, wf ptr, wd ptr, Cout, Cin, first tile}; total = tiles."""
     code = BF16 if dtype == torch.bfloat16 else F32
+    if not desc.is_cuda:
+        raise RuntimeError("stain2stain_amd: the layer descriptor table must live on the GPU")
     _native.check(_L().s2s_pack_conv3x3_batched(code, desc.data_ptr(), desc.shape[0], int(total), _stream()),
                   "pack_conv3x3_batched")
 
@@ -1179,6 +1181,8 @@ def pack_conv4x4_t(w: torch.Tensor, stride: int, dtype: torch.dtype):
 def pack_conv4x4_batched(desc: torch.Tensor, total: int, dtype: torch.dtype) -> None:
     """desc: int64 [nlayers, 7] device tensor {w, wf, wd, Cout, Cin, stride == 2, first block}."""
     code = BF16 if dtype == torch.bfloat16 else F32
+    if not desc.is_cuda:
+        raise RuntimeError("stain2stain_amd: the layer descriptor table must live on the GPU")
     _native.check(_L().s2s_pack_conv4x4_batched(code, desc.data_ptr(), desc.shape[0], int(total), _stream()),
                   "pack_conv4x4_batched")
 
