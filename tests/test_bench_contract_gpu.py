@@ -52,6 +52,19 @@ def test_training_line_has_the_contract_keys():
     assert fp["unit"] == "tiles/s" and 50 < fp["value"] < d["value"] and fp["dtype"].startswith("fp32")
 
 
+def test_dropin_path_is_within_ten_percent_of_the_fused_trainer():
+    """what a user of the reference gets after the ``_target_`` swap -- FlowUNet under autograd inside
+    ConditionalFlowMatchingModule, zero_grad / training_step / backward / optimizer.step with stain2stain_amd.FusedAdam --
+    timed in the default line under the headline's contract, at most 1.10 x the fused trainer's step."""
+    d = _run("--no-pix2pix", "--no-cpu-baseline", steps=16)
+    dr = d["dropin"]
+    assert dr["unit"] == "tiles/s" and dr["dtype"] == "bf16" and "training_step" in dr["metric"]
+    assert dr["fused_adam"]["ms_per_step"] > 0 and dr["torch_adam"]["ms_per_step"] > 0
+    assert abs(dr["vs_fused_trainer"] - dr["ms_per_step"] / d["ms_per_step"]) < 1e-3
+    assert dr["vs_fused_trainer"] <= 1.10, dr
+    assert 0 < dr["fused_adam"]["final_loss"] < 2 and 0 < dr["torch_adam"]["final_loss"] < 2
+
+
 def test_sampling_line():
     d = _run("--mode", "sample", "--euler-steps", "3", "--no-cpu-baseline")
     assert d["unit"] == "tiles/s" and d["config"]["finite"] is True and d["roofline"]["achieved"] > 100
