@@ -200,6 +200,94 @@ def fp32_parity_leg(dev, B: int) -> dict:
                     "headline is held to 4e-3 per op against torch fp32 on bf16-rounded operands"}
 
 
+def multitask_flops(tile: int) -> float:
+    """Algorithmic FLOP per tile of the multitask step: the shared encoder twice, the flow decoder and the mask decoder
+    (same Up blocks, a 1-channel head), forward + data gradient + weight gradient = 3 x forward."""
+    f = FEATURES
+    enc = 2.0 * 9 * (3 * f[0] + f[0] * f[0]) * tile * tile
+    for l in range(1, len(f)):
+        enc += 2.0 * 9 * (f[l - 1] * f[l] + f[l] * f[l]) * (tile >> l) ** 2
+    dec = 0.0
+    for l in range(len(f) - 2, -1, -1):
+        dec += 2.0 * 9 * ((f[l + 1] + f[l]) * f[l] + f[l] * f[l]) * (tile >> l) ** 2
+    heads = 2.0 * f[0] * (3 + 1) * tile * tile
+    return 3.0 * (2 * enc + 2 * dec + heads)
+
+
+def multitask_bench(args, dev, rank: int, world: int, use_dist: bool, tile: int, batch: int, steps: int, warmup: int) -> dict:
+    """BASELINE.json configs[4] (row f2): the multitask step -- shared encoder on xt and on the source, flow head, mask
+    head, Dice + BCE, one Adam over encoder + flow_decoder + seg_decoder (conditional_flow_matching_multitask.py:204-257,
+    391-417) -- as the fused ``MultiTaskTrainer``; 512 x 512 tiles, batch 8 per GPU.  Same timing contract as the headline."""
+    from stain2stain_amd import FlowMatchingDecoder, MultiTaskTrainer, SegmentationDecoder, SharedEncoder, ops
+    torch.manual_seed(1984)
+    enc = SharedEncoder(3, FEATURES, precision=args.precision).to(dev).train()
+    fdec = FlowMatchingDecoder(FEATURES[-1], list(FEATURES[:-1][::-1]), 3, 256, precision=args.precision).to(dev).train()
+    sdec = SegmentationDecoder(FEATURES[-1], list(FEATURES[:-1][::-1]), 1, precision=args.precision).to(dev).train()
+    tr = MultiTaskTrainer(enc, fdec, sdec, time_emb_dim=256, lr=1e-4, weight_decay=1e-5,
+                          sharded_optimizer=args.sharded_optimizer)
+    g = torch.Generator().manual_seed(1984 + rank)
+    pool = [((torch.rand(batch, 3, tile, tile, generator=g) * 2 - 1).to(dev), (torch.rand(batch, 3, tile, tile, generator=g) * 2 - 1).to(dev),
+             (torch.rand(batch, 1, tile, tile, generator=g) > 0.7).float().to(dev)) for _ in range(2)]
+    ts = [torch.rand(batch, generator=g).to(dev) for _ in range(warmup + steps)]
+    for i in range(warmup):
+        tr.step(*pool[i % 2], ts[i])
+    pause = _GcPause()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    every = max(1, args.event_every)
+    prof, timed_steps, loss = [], 0, None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        sampled = i % every == min(every // 2, steps - 1)
+        tr.overlap_wgrad = not sampled
+        if sampled:
+            ops.profile_start(("conv3x3_mfma", "conv3x3_wgrad_mfma"))
+        loss = tr.step(*pool[(warmup + i) % 2], ts[warmup + i])
+        if sampled:
+            prof += ops.profile_stop()
+            timed_steps += 1
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pause.resume()
+    if use_dist:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el)
+    agg = {}
+    for name, work, e0, e1 in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += work
+    n_l, t_l, f_l = agg.get("conv3x3_mfma", [0, 1e-9, 0.0])
+    fl = multitask_flops(tile)
+    return {
+        "metric": f"paired {tile}x{tile} stain tiles/sec (multitask optimisation step: flow + mask heads on a shared encoder)",
+        "value": round(batch * world * steps / elapsed, 3), "unit": "tiles/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"multitask U-Net {FEATURES}: shared encoder x 2 + flow decoder + mask decoder, 3x{tile}x{tile} "
+                               f"tiles, batch {batch}/GPU, CFM MSE + 1.0 x (0.5 Dice + 0.5 BCE), one fused Adam(1e-4, wd 1e-5) "
+                               "(BASELINE.json configs[4]; the reference's 4-domain any2any network is third-party, "
+                               "SURVEY 8d: the in-repo multitask model stands in)",
+                   "global_batch": batch * world, "tile": tile, "parallelism": f"dp{world}",
+                   "final_loss": round(float(loss), 6),
+                   "grad_exchange": (tr.fp.bucketer.mode if tr.fp.bucketer.enabled else "none"),
+                   "algorithmic_gflop_per_tile": round(fl / 1e9, 1),
+                   "step_tflops": round(fl * batch * steps / elapsed / 1e12, 1)},
+        "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
+                     "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": n_l // max(timed_steps, 1), "launches_timed": n_l,
+                     "avg_launch_ms": round(t_l * 1e3 / max(n_l, 1), 4)},
+        "kernels": {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / max(timed_steps, 1), 4),
+                        **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {})}
+                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+
+
 def dropin_leg(dev, B: int, steps: int, fused_ms: float) -> dict:
     """The path a user of the reference gets after the ``_target_`` swap: ``FlowUNet`` under autograd inside
     ``ConditionalFlowMatchingModule`` driven the way Lightning's automatic optimisation drives the reference's
@@ -381,7 +469,7 @@ def main() -> None:
                     help="bracket the conv launches of every N-th timed step with HIP events for the roofline leg "
                          "(1 = every step).  A bracketed step runs on ONE stream so that a bracket times its kernel alone: "
                          "it takes ~0.9 ms longer than an overlapped step, so N = 8 cost the line 1.4 %%, 16 costs 0.7 %%")
-    ap.add_argument("--mode", default="train", choices=["train", "sample", "pix2pix"],
+    ap.add_argument("--mode", default="train", choices=["train", "sample", "pix2pix", "multitask"],
                     help="train = the headline optimisation step (default); sample = BASELINE.json configs[3], "
                          "50 fixed Euler steps of the eval-mode network on a batch of 32 tiles (secondary line)")
     ap.add_argument("--euler-steps", type=int, default=50)
@@ -423,6 +511,16 @@ def main() -> None:
 
     from stain2stain_amd import CFMTrainer, FlowUNet, euler_generate, ops
 
+    if args.mode == "multitask":
+        # BASELINE.json configs[4] defaults: 512 x 512 tiles, batch 8 per GPU (--tile / --batch override them)
+        tile = args.tile if args.tile != 256 else 512
+        batch = args.batch if args.batch != BATCH_PER_GPU else 8
+        res = multitask_bench(args, dev, rank, world, use_dist, tile, batch, args.steps, args.warmup)
+        if rank == 0:
+            _emit(json.dumps(res))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if args.mode == "pix2pix":
         res = pix2pix_bench(args, dev, rank, world, use_dist)
         if rank == 0:
@@ -649,6 +747,9 @@ def main() -> None:
         extras["fp32_parity"] = fp32_parity_leg(dev, B)
         torch.cuda.empty_cache()
         extras["dropin"] = dropin_leg(dev, B, max(5, args.steps // 2), out["ms_per_step"])
+        torch.cuda.empty_cache()
+        mt = multitask_bench(args, dev, rank, world, use_dist, 512, 8, max(4, args.steps // 2), 2)
+        extras["multitask"] = {k: mt[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "kernels")}
         torch.cuda.empty_cache()
     if not args.no_pix2pix and default_line:
         del trainer, net

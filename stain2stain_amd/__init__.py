@@ -17,10 +17,11 @@ from .pix2pix import (Conv4x4Stride1, Conv4x4Stride2, ConvTranspose4x4Stride2, I
 from .pix2pix_engine import Pix2PixTrainer
 from .trainer import CFMTrainer
 from .optim import FusedAdam
+from .multitask_trainer import MultiTaskTrainer
 
 __all__ = ["SharedEncoder", "FlowMatchingDecoder", "SegmentationDecoder", "TimeEmbedding", "FlowUNet",
            "ConditionalFlowMatcher", "ConditionalFlowMatchingModule", "MultiTaskFlowMatchingModule", "euler_generate", "dopri5_generate", "euler_integrate", "dopri5_integrate", "SolverConfig", "GraphedVelocity",
            "CFMTrainer", "ClassConditionalFlowUNet", "ClassConditionalFlowMatchingModule",
            "MaskConditionedFlowMatchingModule", "ROICharbonnierFlowMatchingModule", "ROIWeightedFlowMatchingModule",
            "checkpoint", "InstanceNormLeakyReLU", "Conv4x4Stride1", "Conv4x4Stride2", "ConvTranspose4x4Stride2",
-           "Pix2PixGenerator", "PatchGANDiscriminator", "Pix2PixTrainer", "FusedAdam"]
+           "Pix2PixGenerator", "PatchGANDiscriminator", "Pix2PixTrainer", "FusedAdam", "MultiTaskTrainer"]
