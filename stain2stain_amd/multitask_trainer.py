@@ -157,8 +157,7 @@ class MultiTaskTrainer:
         else:
             seg3, dz = ops.seg_loss(logits, mask.float().reshape(logits.shape), self.dice_smooth, self.dice_weight,
                                     want_grad=True, grad_scale=w)
-        total = flow.reshape(1).clone()
-        ops.axpy_(total, seg3[0:1], w)                                   # total = flow + w * seg
+        total = flow + w * seg3[0]                                       # (two device scalars: the logged total, :249)
         self.fp.bucketer.start_step()
         self._group = 0
         engine.side_stream = self._side if self.overlap_wgrad else None
@@ -175,7 +174,7 @@ class MultiTaskTrainer:
             engine.side_stream = None
         engine.join_side(self._side)
         second = "seg_ce" if self.num_classes is not None else "seg_bce"
-        losses = {"total": total[0], "flow": flow, "seg": seg3[0], "seg_dice": seg3[1], second: seg3[2]}
+        losses = {"total": total, "flow": flow, "seg": seg3[0], "seg_dice": seg3[1], second: seg3[2]}
         return losses, ({"v": v, "logits": logits} if want_outputs else None)
 
     def optimizer_step(self) -> None:
