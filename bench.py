@@ -79,6 +79,33 @@ def cpu_baseline(seconds_budget: float = 30.0):
                       f"torch {torch.__version__} CPU, {threads} threads"}
 
 
+def pix2pix_cpu_baseline(seconds_budget: float = 20.0):
+    """The pix2pix G + D step of the torch-layer oracle (oracle/pix2pix_oracle.py: the checker of row a13, builder-authored
+    because the reference has no such model) timed on this box's host cores: headline networks, batch 2, fp32."""
+    from oracle import pix2pix_oracle as PO
+    torch.manual_seed(1984)
+    G, D = PO.OracleGenerator(), PO.OracleDiscriminator()
+    og = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(1984)
+    b = 2
+    src = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
+    tgt = torch.rand(b, 3, TILE, TILE, generator=g) * 2 - 1
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    PO.pix2pix_step(G, D, og, od, src, tgt)           # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        PO.pix2pix_step(G, D, og, od, src, tgt)
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 6 or el > seconds_budget:
+            break
+    return {"value": round(b * n / el, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"same networks and G + D step (torch layers, fp32, two torch.optim.Adam) at batch {b}, 1 warm-up + "
+                      f"{n} timed steps, torch {torch.__version__} CPU, {threads} threads"}
+
+
 def pix2pix_flops(batch: int, tile: int, ngf: int = 64, ndf: int = 64, num_downs: int = 8) -> dict:
     """Algorithmic FLOP of one pix2pix G + D step (row a13), real channel counts (3-channel images, 1 logit channel):
     2 MAC per weight tap and output pixel; forward, data gradient and weight gradient of every layer that needs them."""
@@ -96,8 +123,14 @@ def pix2pix_flops(batch: int, tile: int, ngf: int = 64, ndf: int = 64, num_downs
     d_fwd = sum(2.0 * o * o * co * 16 * ci for ci, co, o in d_layers)
     # G: fwd + dgrad + wgrad.  D: forward on 2B (update) + B (generator pass); weight gradients on 2B; data gradients
     # on 2B (update, all but the first layer) + B (generator pass)
+    g_first = 2.0 * (tile >> 1) ** 2 * ch[0] * 16 * 3                   # downs.0: its data gradient is never formed
+    d_first = 2.0 * d_layers[0][2] ** 2 * d_layers[0][1] * 16 * d_layers[0][0]
+    # what the engine LAUNCHES in the forward / data-gradient group, real channel counts: G forward + data gradients (all
+    # but downs.0); D forward on 2B + B; D data gradients on 2B (all but c1: the update needs no input gradient) + B (all)
+    conv_fd = batch * ((2 * g_fwd - g_first) + 3 * d_fwd + 2 * (d_fwd - d_first) + d_fwd)
     return {"generator": batch * 3 * g_fwd, "discriminator": batch * (3 * d_fwd + 2 * d_fwd + 3 * d_fwd),
-            "g_fwd_per_tile": g_fwd, "d_fwd_per_tile": d_fwd}
+            "g_fwd_per_tile": g_fwd, "d_fwd_per_tile": d_fwd, "conv_fwd_dgrad_launched": conv_fd,
+            "generator_launched": batch * (3 * g_fwd - g_first)}
 
 
 def _committed_traffic(fname: str, prefix: str):
@@ -109,6 +142,19 @@ def _committed_traffic(fname: str, prefix: str):
         return next(v["hbm_bytes_per_launch_corrected"] for k, v in tj.items() if k.startswith(prefix))
     except Exception:  # noqa: BLE001
         return None
+
+
+def rccl_object(dev, world: int, use_dist: bool):
+    """Which collective backend the line ran on and which ranks took part (an all-gather of the rank ids over the very
+    process group the gradient exchange uses), so that a scaling record proves its N ranks."""
+    if not use_dist:
+        return {"backend": None, "world": 1, "ranks_seen": [0]}
+    mine = torch.tensor([dist.get_rank()], device=dev, dtype=torch.int64)
+    seen = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(seen, mine)
+    backend = dist.get_backend()
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world": dist.get_world_size(),
+            "ranks_seen": sorted(int(t) for t in seen)}
 
 
 def _launch_note(graph: bool) -> str:
@@ -139,6 +185,7 @@ def _other_leg(trainer, step_fn, steps: int, use_dist: bool):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / n
     pause.resume()
+    trainer.close()               # the captured graph goes now (owned lifetime), not at interpreter exit
     trainer.graph = was
     return round(ms, 3)
 
@@ -170,6 +217,9 @@ def sample_leg(dev) -> dict:
                                                   "tiles_per_s": round(B * 1e3 / ms, 2), "solves_timed": n,
                                                   "finite": bool(torch.isfinite(x).all())}
         out[f"batch{B}"] = res
+        g = getattr(net, "_s2s_euler_graph", None)
+        if g is not None:
+            g.close()
     out["value"] = out["batch32"]["graph"]["tiles_per_s"]
     return out
 
@@ -410,15 +460,26 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
     #  available to the builder, and nothing untested goes between the timed region and the JSON line of a scaling run)
     other_ms = (_other_leg(tr, lambda i: tr.step(*data[i % 4]), steps, use_dist)
                 if (graph_ok and world == 1 and not args.no_extras) else None)
-    agg = {}
+    agg, by_net = {}, {}
     for name, work, e0, e1 in prof:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += work
-    n_l, t_l, f_l = agg.get("convkxk_mfma", [0, 1e-9, 0.0])
+        base, _, net = name.partition("@")          # brackets are tagged with the network whose pass issued them
+        dt_s = e0.elapsed_time(e1) * 1e-3
+        a = agg.setdefault(base, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += dt_s; a[2] += work
+        b = by_net.setdefault((base, net), [0, 0.0])
+        b[0] += 1; b[1] += dt_s
+    n_l, t_l, _ = agg.get("convkxk_mfma", [0, 1e-9, 0.0])
     traffic = _committed_traffic("pix2pix_hbm_traffic_current.json", "convkxk") if (
         B == BATCH_PER_GPU and args.precision == "bf16" and TILE == 256) else None
     fl = pix2pix_flops(B, TILE)
     step_flop = fl["generator"] + fl["discriminator"]
+    ts = max(timed_steps, 1)
+    f_l = fl["conv_fwd_dgrad_launched"] * ts       # REAL channel counts (3-channel images, 1 logit), not the padded 8
+    # the generator's conv stack as north_star words its target: forward + data gradient + weight gradient (fold
+    # included) launches of the 16 generator layers over their algorithmic FLOP
+    g_t = sum(v[1] for (base, net), v in by_net.items() if net == "G" and base in ("convkxk_mfma", "convkxk_wgrad_mfma"))
+    g_n = sum(v[0] for (base, net), v in by_net.items() if net == "G" and base in ("convkxk_mfma", "convkxk_wgrad_mfma"))
+    gen_tflops = fl["generator_launched"] * ts / max(g_t, 1e-9) / 1e12
     return {
         "metric": f"paired {TILE}x{TILE} stain tiles/sec (pix2pix G+D optimisation step)",
         "value": round(B * world * steps / elapsed, 3), "unit": "tiles/s", "n_gpus": world, "steps": steps,
@@ -442,7 +503,15 @@ def pix2pix_bench(args, dev, rank: int, world: int, use_dist: bool) -> dict:
                                      "(rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/pix2pix_hbm_traffic_current.json)",
                      "launches_per_step": n_l // max(timed_steps, 1), "launches_timed": n_l,
                      "avg_launch_ms": round(t_l * 1e3 / max(n_l, 1), 4),
-                     "note": "FLOP counted on the padded channel counts the kernel executes (8-channel images)"},
+                     "note": "FLOP = 2 MAC per tap and output pixel on the REAL channel counts (3-channel images, one "
+                             "logit channel) of the launches the step issues; brackets on one stream"},
+        "generator_conv_frac": round(gen_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+        "generator_conv": {"tflops": round(gen_tflops, 1), "launches_per_step": g_n // ts,
+                           "ms_per_step": round(g_t * 1e3 / ts, 4),
+                           "gflop_per_step": round(fl["generator_launched"] / 1e9, 1),
+                           "what": "forward + data-gradient + weight-gradient launches of the 16 generator layers "
+                                   "(HIP-event brackets), the stack BASELINE.json's 40 % target names"},
+        "launches_per_step": (sum(v[0] for v in agg.values()) // ts) if args.breakdown else None,
         "kernels": {k: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 / max(timed_steps, 1), 4),
                         **({"tflops": round(v[2] / v[1] / 1e12, 1)} if v[2] else {})}
                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
@@ -733,6 +802,9 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    rc = rccl_object(dev, world, use_dist)            # (a collective: every rank calls)
+    if rank == 0:
+        out["rccl"] = rc
     # BASELINE.json's metric is worded on the pix2pix G + D step, which the reference does not contain:
     # that step is timed right after the reference-parity line, under the same contract, and reported under "pix2pix"
     p2p = None
@@ -759,7 +831,9 @@ def main() -> None:
         out.update(extras)
         if p2p is not None:
             out["pix2pix"] = {k: p2p[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
-                                                  "kernels")}
+                                                  "generator_conv_frac", "generator_conv", "kernels")}
+            if world == 1 and not args.no_cpu_baseline:
+                out["pix2pix"]["cpu_baseline"] = pix2pix_cpu_baseline()
         _emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

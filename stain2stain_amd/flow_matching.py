@@ -107,6 +107,8 @@ def euler_generate(net, source_img: torch.Tensor, num_steps: int = 50, graph: bo
         dt = 1.0 / num_steps
         g = getattr(net, "_s2s_euler_graph", None)
         if g is None or not g.matches(net, x, dt):
+            if g is not None:
+                g.close()                  # the superseded graph goes now, not whenever the cyclic collector finds it
             g = GraphedVelocity(net, x, dt)
             try:
                 object.__setattr__(net, "_s2s_euler_graph", g)      # a plain attribute, not a registered sub-module
@@ -158,6 +160,17 @@ class GraphedVelocity:
             if dt is not None:
                 ops.axpy_(self.x, self.v, dt)
 
+    def close(self) -> None:
+        """Release the graph and its private pool now (the object sits in a cycle with its network through
+        ``net._s2s_euler_graph``; see CFMTrainer.close)."""
+        self.graph = None
+        self.v = None
+        if getattr(self.net, "_s2s_euler_graph", None) is self:
+            try:
+                object.__delattr__(self.net, "_s2s_euler_graph")
+            except Exception:  # noqa: BLE001
+                pass
+
     def matches(self, net, x: torch.Tensor, dt: Optional[float]) -> bool:
         from . import engine
         return net is self.net and self.key == (tuple(x.shape), dt, engine.mutation_epoch[0],
@@ -207,7 +220,10 @@ def dopri5_generate(net, source_img: torch.Tensor, atol: float = 1e-4, rtol: flo
         if not graph:
             return dopri5_integrate(net, x, atol, rtol, max_steps, return_stats)
         gv = GraphedVelocity(net, x, None)
-        return dopri5_integrate(lambda t, y: gv(t, y).clone(), x, atol, rtol, max_steps, return_stats)
+        try:
+            return dopri5_integrate(lambda t, y: gv(t, y).clone(), x, atol, rtol, max_steps, return_stats)
+        finally:
+            gv.close()
 
 
 @torch.no_grad()

@@ -108,6 +108,12 @@ _WORKSPACE = {}
 
 
 def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
+    # A step that is being CAPTURED bakes the buffer's address into the graph, and a replay is not ordered against a later
+    # host-side replacement of the process-global buffer (a second, wider trainer on the same stream growing it would
+    # return the old block to the allocator while the graph still writes its slabs there: ADVICE r3).  So a capture gets
+    # an allocation of its own, which lives in the graph's private memory pool for as long as the graph does.
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((max(numel, 1),), dtype=torch.float32, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream())
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < numel:
@@ -121,6 +127,7 @@ def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 _PROFILE: Optional[list] = None
 _PROFILE_ONLY: Optional[set] = None
+PROFILE_TAG = ""          # set by the engines around a network's passes ("G" / "D"): bench.py attributes brackets by it
 
 
 def profile_start(only=None) -> None:
@@ -237,7 +244,7 @@ def _timed(name: str, work_fn=None):
             e0.record()
             out = fn(*args, **kwargs)
             e1.record()
-            _PROFILE.append((name, work_fn(*args, **kwargs) if work_fn else 0.0, e0, e1))
+            _PROFILE.append((name + ("@" + PROFILE_TAG if PROFILE_TAG else ""), work_fn(*args, **kwargs) if work_fn else 0.0, e0, e1))
             return out
         wrapped.__name__ = fn.__name__
         wrapped.__doc__ = fn.__doc__
@@ -769,8 +776,13 @@ class capture_graph:
         self._gc = gc.isenabled()
         gc.collect()
         gc.disable()
-        torch.cuda.synchronize()
-        return self._ctx.__enter__()
+        try:
+            torch.cuda.synchronize()
+            return self._ctx.__enter__()
+        except BaseException:          # a failed entry never reaches __exit__: put the collector back here
+            if self._gc:
+                gc.enable()
+            raise
 
     def __exit__(self, *exc):
         import gc

@@ -341,6 +341,16 @@ def _runner(net, precision: str):
     return r
 
 
+def _check_versions(net, versions, what: str) -> None:
+    """The backward pass reads the runner's PACKED operands, which ``refresh()`` re-packs in place whenever a parameter
+    changes: a backward through a forward that ran on older weights (forward, in-place optimiser step, second forward,
+    THEN the first output's backward) would silently use the new ones -- raise, as torch's own layers do ("modified by an
+    inplace operation")."""
+    if tuple(p._version for p in net.parameters()) != versions:
+        raise RuntimeError(f"{what}: a parameter needed for the gradient computation has been modified by an inplace "
+                           "operation since this forward pass (run backward before the optimiser step)")
+
+
 def _check_image(x: torch.Tensor, channels: int, what: str) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("stain2stain_amd: the pix2pix networks run on the GPU only (no CPU fallback)")
@@ -363,6 +373,7 @@ class _GeneratorFn(torch.autograd.Function):
         ref = src if src.shape[1] == C else fake                 # (the kernel's L1 / D-input outputs are not used here)
         ops.p2p_tanh_l1_fwd(g.h, ref, ref, torch.empty((B, H, W, 8), dtype=r.dtype, device=src.device), fake)
         ctx.runner, ctx.g, ctx.net = r, g, net
+        ctx.versions = tuple(p._version for p in net.parameters())
         return fake
 
     @staticmethod
@@ -372,6 +383,7 @@ class _GeneratorFn(torch.autograd.Function):
             raise RuntimeError("Pix2PixGenerator: the activations of this forward pass were released by its first backward")
         if ctx.needs_input_grad[1]:
             raise RuntimeError("Pix2PixGenerator: no gradient with respect to the input image")
+        _check_versions(net, ctx.versions, "Pix2PixGenerator")
         B, H, W, _ = g.h.shape
         gf = gfake.contiguous().float()
         # d(pre-tanh) = gfake * (1 - fake^2): the tanh backward kernel with the L1 term switched off and the upstream
@@ -400,6 +412,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         d_in = ops.p2p_pack_input(a32, b32, torch.empty((B, H, W, 8), dtype=r.dtype, device=a32.device))
         z, saved = r.d_forward(d_in)
         ctx.runner, ctx.saved, ctx.net, ctx.ca, ctx.cb = r, saved, net, ca, net.in_channels - ca
+        ctx.versions = tuple(p._version for p in net.parameters())
         return ops.p2p_unpack(z, 0, 1)
 
     @staticmethod
@@ -407,6 +420,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         r, net = ctx.runner, ctx.net
         if ctx.saved is None:
             raise RuntimeError("PatchGANDiscriminator: the activations of this forward pass were released by its first backward")
+        _check_versions(net, ctx.versions, "PatchGANDiscriminator")
         gz = gz.contiguous().float()
         B, _, h, w = gz.shape
         dz = ops.p2p_pack_input(gz, None, torch.empty((B, h, w, 8), dtype=r.dtype, device=gz.device))

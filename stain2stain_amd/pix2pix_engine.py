@@ -40,6 +40,16 @@ LRELU = 0.2
 FOLD_IN_NORM = os.environ.get("S2S_P2P_FOLD_IN_NORM", "1") != "0"
 
 
+def _check_norms(net) -> None:
+    """The fused passes hard-wire InstanceNorm2d(affine=False, eps=1e-5), the form both networks are built with: a norm
+    module edited to anything else must not be silently ignored."""
+    from .pix2pix import InstanceNormLeakyReLU
+    for name, m in net.named_modules():
+        if isinstance(m, InstanceNormLeakyReLU) and (abs(m.eps - 1e-5) > 1e-12 or m.weight is not None):
+            raise NotImplementedError(f"stain2stain_amd: {name}: the fused pix2pix passes implement "
+                                      "InstanceNorm2d(affine=False, eps=1e-5) only")
+
+
 class FlatParams:
     """Parameters of one network as views of a flat fp32 buffer + flat gradient / Adam-moment buffers.
 
@@ -269,6 +279,8 @@ class Pix2PixTrainer:
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.G, self.D = G, D
+        _check_norms(G)
+        _check_norms(D)
         self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
         self.lr, self.betas, self.eps, self.wd, self.lambda_l1 = lr, tuple(betas), eps, weight_decay, lambda_l1
         self.pg, self.sync_loss = process_group, sync_loss
@@ -547,7 +559,9 @@ class Pix2PixTrainer:
         dev, dt = src.device, self.dtype
         src, tgt = src.contiguous().float(), tgt.contiguous().float()
         losses = torch.zeros((8,), dtype=torch.float32, device=dev)
+        ops.PROFILE_TAG = "G"
         gctx = self.g_forward(src)
+        ops.PROFILE_TAG = "D"
         d_in = torch.empty((2 * B, H, W, 8), dtype=dt, device=dev)          # [real pairs | fake pairs]
         ops.p2p_pack_input(src, tgt, d_in[:B])
         fake = torch.empty((B, C, H, W), dtype=torch.float32, device=dev) if want_fake else None
@@ -570,6 +584,7 @@ class Pix2PixTrainer:
         _, dzg = ops.p2p_bce_logits(zg, B, 1.0 / (B * npatch), 0.0, out=losses[2:4])
         gd = self.d_backward(saved_g, dzg, want_w=False, need_input_grad=True)
         dh = ops.p2p_tanh_l1_bwd(gctx.h, tgt, gd, self.lambda_l1 / (B * C * H * W))
+        ops.PROFILE_TAG = "G"
         engine.side_stream = self._side if self.overlap_wgrad else None
         in_bwd = update and self.opt_in_backward and not self.pG.bucketer.enabled
         self.g_backward(gctx, dh, update=in_bwd, hyper_dev=hyper_dev)
@@ -579,6 +594,7 @@ class Pix2PixTrainer:
             self.packG.repack()
         elif not update:
             self.pG.bucketer.wait_all()
+        ops.PROFILE_TAG = ""
         return losses, fake
 
     @staticmethod
@@ -636,6 +652,16 @@ class Pix2PixTrainer:
                                         self.pG.bucketer.grad_scale))
         graph.replay()
         return losses.clone()
+
+    def close(self) -> None:
+        """Drop the captured graph, its static buffers and the pinned Adam-scalar ring now (see CFMTrainer.close)."""
+        self._captured, self._warm_key, self._hyper = None, None, None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     @torch.no_grad()
     def generate(self, src: torch.Tensor) -> torch.Tensor:
@@ -703,6 +729,7 @@ class NetRunner:
         if self._key is None or self._key[0] != ptrs:
             if next(net.parameters()).device.type != "cuda":
                 raise RuntimeError("stain2stain_amd: the pix2pix networks run on the GPU only (no CPU fallback)")
+            _check_norms(net)
             if self.is_generator:
                 self.n = len(net.downs)
                 self.g_down = [_Layer(f"downs.{i}", "s2", m.weight, m.bias) for i, m in enumerate(net.downs)]

@@ -326,11 +326,22 @@ class CFMTrainer:
         if self._hyper is None:
             self._hyper = ops.AdamHyperRing(x0.device)
         key = (tuple(x0.shape), x0.device, self.overlap_wgrad)
-        self.step_count += 1
+        if self.bucketer.enabled and not CFMTrainer._warned_multi_rank_graph:
+            CFMTrainer._warned_multi_rank_graph = True
+            import warnings
+            warnings.warn("stain2stain_amd: graph=True with a gradient exchange captures the RCCL collectives; this has "
+                          "only been exercised at world size 1 (S2S_FORCE_DDP) -- treat it as experimental", stacklevel=3)
+        # the step counter moves only once the step has run (a failed capture must not count as a step)
+        step = self.step_count + 1
         if self._captured is None or self._captured.key != key:
             if self._warm_key != key:       # first step of this shape: eager (module load, LDS attributes, workspaces)
                 self._warm_key, self._captured = key, None
-                loss = self._step_body(x0, x1, t, None)
+                self.step_count = step
+                try:
+                    loss = self._step_body(x0, x1, t, None)
+                except BaseException:
+                    self.step_count = step - 1
+                    raise
                 engine.mutation_epoch[0] += 1
                 return loss
             cap = _CapturedStep(key, x0, x1, t)
@@ -340,11 +351,26 @@ class CFMTrainer:
             self._captured = cap
         cap = self._captured
         cap.x0.copy_(x0); cap.x1.copy_(x1); cap.t.copy_(t)
-        self._hyper.push(ops.adam_hyper(self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+        self._hyper.push(ops.adam_hyper(step, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                         self.bucketer.grad_scale))
         cap.graph.replay()
+        self.step_count = step
         engine.mutation_epoch[0] += 1
         return cap.loss.clone()
+
+    _warned_multi_rank_graph = False
+
+    def close(self) -> None:
+        """Drop the captured graph, its static buffers and the pinned Adam-scalar ring while torch and the HIP runtime are
+        fully alive (a captured step sits in a reference cycle with its trainer; left to the cyclic collector it may be
+        destroyed during another capture or at interpreter exit, in an order the runtime does not define)."""
+        self._captured, self._warm_key, self._hyper = None, None, None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class _CapturedStep:

@@ -149,6 +149,7 @@ def _rccl_main(rank, port, out_dir):
         gl = [float(gtr.step(x0.cuda(), x1.cuda(), t[s].cuda())) for s in range(2)]
         torch.cuda.synchronize()
         graph_ok = gtr._captured is not None and torch.equal(gtr.flat_p.cpu(), ref_p) and gl == [ref[0][1], ref[1][1]]
+        gtr.close()
     except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test with the message
         graph_ok, graph_err = False, repr(e)[:500]
     torch.save({"ok": bool(ok), "buckets": len(tr.bucketer.buckets), "graph_ok": bool(graph_ok), "graph_err": graph_err},

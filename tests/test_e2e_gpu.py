@@ -365,3 +365,5 @@ def test_graph_captured_sampler_equals_the_eager_one(golden_tiny):
         net.flow_decoder.outc.bias.add_(0.25)                      # new parameters: the capture must be rebuilt
     moved = euler_generate(net, x, n, graph=True)
     assert not torch.equal(moved, eager) and torch.equal(moved, euler_generate(net, x, n))
+    net._s2s_euler_graph.close()                                   # owned lifetime: the capture goes with its user
+    assert getattr(net, "_s2s_euler_graph", None) is None

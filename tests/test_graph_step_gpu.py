@@ -38,6 +38,8 @@ def test_cfm_graph_step_is_bit_equal_to_eager(prec):
                        {k: v.detach().cpu().clone() for k, v in net.named_buffers()})
         if graph:
             assert tr._captured is not None and tr.step_count == len(data)
+            tr.close()
+            assert tr._captured is None
     assert torch.equal(runs[True][0], runs[False][0]), (runs[True][0], runs[False][0])
     for i, (a, b) in enumerate(zip(runs[True][1], runs[False][1])):
         assert torch.equal(a, b), f"parameters differ after step {i}"
@@ -58,6 +60,7 @@ def test_cfm_graph_step_at_production_width_matches_eager_and_takes_fewer_host_c
         ls = [tr.step(*d).clone() for d in data]
         torch.cuda.synchronize()
         out[graph] = (torch.stack(ls).cpu(), tr.flat_p.cpu())
+        tr.close()
         del tr, net
         torch.cuda.empty_cache()
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
@@ -82,6 +85,7 @@ def test_pix2pix_graph_step_is_bit_equal_to_eager(prec):
         runs[graph] = (torch.stack(ls).cpu(), [p.cpu() for p in pg], [p.cpu() for p in pd])
         if graph:
             assert tr._captured is not None and tr.pG.step_count == tr.pD.step_count == len(data)
+            tr.close()
     assert torch.equal(runs[True][0], runs[False][0])
     for i in range(len(data)):
         assert torch.equal(runs[True][1][i], runs[False][1][i]), f"generator differs after step {i}"
@@ -149,3 +153,39 @@ def test_pix2pix_split_k_folded_in_the_norm_is_bit_equal_to_separate_reduce_laun
     for i, (a, b) in enumerate(zip(runs[True], runs[False])):
         for x, y in zip(a, b):
             assert torch.equal(x, y), f"step {i}"
+
+
+def test_captured_step_owns_its_workspaces():
+    """a captured step bakes the addresses of its split-K / weight-gradient slabs into the graph, and a replay is
+    not ordered against a later host-side replacement of a process-global buffer.  A capture therefore allocates its
+    workspaces itself (graph-private pool): growing the shared buffers afterwards -- a second, wider trainer on the same
+    streams -- and recycling the memory they used to occupy must not change what the replays compute."""
+    from stain2stain_amd import CFMTrainer, FlowUNet, ops
+    data = _batches(6, 4, 64, 11)
+
+    def run(disturb):
+        torch.manual_seed(7)
+        net = FlowUNet(3, [16, 32, 64], 3, 32).to(DEV).train()
+        tr = CFMTrainer(net, lr=1e-3, weight_decay=1e-5, graph=True)
+        out = [tr.step(*data[0]).clone(), tr.step(*data[1]).clone()]          # eager warm-up, then the capture
+        assert tr._captured is not None
+        if disturb:
+            torch.manual_seed(8)
+            wide = CFMTrainer(FlowUNet(3, [32, 64, 128, 256], 3, 32).to(DEV).train(), lr=1e-3)
+            g = torch.Generator().manual_seed(12)
+            big = ((torch.rand(8, 3, 128, 128, generator=g) * 2 - 1).to(DEV), (torch.rand(8, 3, 128, 128, generator=g) * 2 - 1).to(DEV),
+                   torch.rand(8, generator=g).to(DEV))
+            wide.step(*big)                                                    # grows every shared workspace
+            torch.cuda.synchronize()
+            del wide
+            torch.cuda.empty_cache()
+            junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(16)]      # recycle what was freed
+        for d in data[2:]:
+            out.append(tr.step(*d).clone())
+        torch.cuda.synchronize()
+        res = (torch.stack(out).cpu(), tr.flat_p.cpu())
+        tr.close()
+        return res
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -472,3 +472,31 @@ def test_headline_networks_fp32_gradients_against_the_oracle():
             worst = (l2, k, yard)
     print(f"headline fp32 gradients: fake {relerr(fake, fake_o):.2e}; worst L2 error {worst[0]:.2e} on {worst[1]} "
           f"(the oracle's own fp32-vs-fp64 deviation there: {worst[2]:.2e})")
+
+
+def test_module_backward_after_an_inplace_parameter_update_raises():
+    """the module face's backward reads the runner's packed operands, which are re-packed in place when a
+    parameter changes.  forward (W0) -> optimiser step -> forward (W1) -> backward of the FIRST output would silently use
+    W1; it raises instead, as torch's own layers do.  A norm module edited away from InstanceNorm2d(affine=False, 1e-5) is
+    refused as well."""
+    from stain2stain_amd.pix2pix import PatchGANDiscriminator, Pix2PixGenerator
+    torch.manual_seed(2)
+    G = Pix2PixGenerator(ngf=16, num_downs=5).to(DEV)
+    D = PatchGANDiscriminator(ndf=16).to(DEV)
+    x = torch.rand(2, 3, 64, 64, device=DEV) * 2 - 1
+    for net, call in ((G, lambda: G(x)), (D, lambda: D(x, x))):
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        y0 = call()
+        y0.sum().backward()                     # fine: nothing changed in between
+        opt.step()
+        opt.zero_grad()
+        y1 = call()
+        opt2 = torch.optim.SGD(net.parameters(), lr=0.1)
+        call().sum().backward()
+        opt2.step()                             # parameters move in place while y1's graph is alive
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            y1.sum().backward()
+    G.down_norms[0].eps = 1e-3
+    G.__dict__.pop("_runner_obj", None)
+    with pytest.raises(NotImplementedError, match="InstanceNorm2d"):
+        G(x)
