@@ -217,9 +217,9 @@ def sample_leg(dev) -> dict:
                                                   "tiles_per_s": round(B * 1e3 / ms, 2), "solves_timed": n,
                                                   "finite": bool(torch.isfinite(x).all())}
         out[f"batch{B}"] = res
-        g = getattr(net, "_s2s_euler_graph", None)
-        if g is not None:
-            g.close()
+        cap = getattr(net, "_s2s_euler_graph", None)
+        if cap is not None:
+            cap.close()
     out["value"] = out["batch32"]["graph"]["tiles_per_s"]
     return out
 
