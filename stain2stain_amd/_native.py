@@ -45,7 +45,8 @@ def needs_build(lib_path: str = None) -> bool:
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 4, ablate: bool = False) -> str:
     """Compile every HIP source for gfx950 and link the shared library in-tree.  ``ablate``: the -DS2S_ABLATE variant
-    (libstain2stain_hip_ablate.so, for scripts/ -- set S2S_LIB=ablate before importing the package to load it)."""
+    (libstain2stain_hip_ablate.so: timing ablations whose results are wrong by construction; ``scripts/ablate_lib.py``
+    builds and loads it explicitly -- the package itself never does, whatever the environment says)."""
     if ablate:
         if not force and not needs_build(ABLATE_LIB_PATH):
             return ABLATE_LIB_PATH
@@ -122,10 +123,7 @@ def lib() -> ctypes.CDLL:
     """Load (never build implicitly on a GPU box unless the .so is missing) and return the library."""
     global _lib
     if _lib is None:
-        if os.environ.get("S2S_LIB") == "ablate":          # scripts/ only (timing ablations; results may be wrong)
-            build(ablate=True, jobs=6)         # (no-op when the library is newer than every source)
-            _lib = ctypes.CDLL(ABLATE_LIB_PATH)
-        elif not os.path.exists(LIB_PATH):
+        if not os.path.exists(LIB_PATH):
             import fcntl                   # one rank of a multi-process launch builds, the others wait for it
             with open(os.path.join(HERE, ".build.lock"), "w") as lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
@@ -143,6 +141,23 @@ def lib() -> ctypes.CDLL:
             fn = getattr(_lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
+    return _lib
+
+
+def load_library(path: str) -> ctypes.CDLL:
+    """Bind ``path`` instead of the product library.  For scripts/ablate_lib.py only (the -DS2S_ABLATE build): it must be
+    called before anything else has loaded the library, and it says loudly what it did."""
+    global _lib
+    if _lib is not None:
+        raise RuntimeError("stain2stain_amd: a library is already loaded; load_library() must come first")
+    import sys
+    print(f"stain2stain_amd: LOADING {path} INSTEAD OF THE PRODUCT LIBRARY -- results of this process are not to be trusted",
+          file=sys.stderr)
+    _lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in declared_prototypes().items():
+        fn = getattr(_lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
     return _lib
 
 

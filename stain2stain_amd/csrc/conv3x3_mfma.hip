@@ -85,11 +85,9 @@ struct Conv3x3Args {
              // 32x32x16 loop, bit1 = no MFMA, bit2 = no halo DMA, 8 = no global stores, 16 = no epilogue
 };
 
-// S2S_CONV_EPI=lds: the LDS-staged epilogue also for launches without statistics (A/B switch; same results)
-static int direct_ep_default() {
-  static const int v = [] { const char* e = getenv("S2S_CONV_EPI"); return !(e && e[0] == 'l'); }();
-  return v;
-}
+// launches without statistics store straight from the accumulators (conv_epilogue16_direct; the LDS-staged epilogue stays
+// for the launches that take BatchNorm partials through it)
+static int direct_ep_default() { return 1; }
 
 namespace {
 
@@ -1417,7 +1415,7 @@ inline PersPlan pers_plan(const Conv3x3Args& a, int GX, int GY) {
       if (!p.xsp || cost < best) { best = cost; p.xsp = sp; p.xsn = sn; }
     }
   }
-  static const int slots = [] { const char* e = getenv("S2S_CONV_PERS_WGS"); return e ? atoi(e) : 512; }();   // 2 per CU
+  constexpr int slots = 512;                           // 2 per CU (swept in round 3: no better grid)
   int grid = (int)(ntiles < slots ? ntiles : slots);
   if (p.xsp && grid > 8) grid -= grid % 8;             // a stride that is a multiple of 8 keeps a workgroup inside its XCD's block
   p.grid = grid < 1 ? 1 : grid;
@@ -1916,15 +1914,10 @@ __global__ __launch_bounds__(256, 1) void convflat_dma16_kernel(Conv3x3Args a) {
   }
 }
 
-template <int BN, int MODE, int NS = 8>
+template <int BN, int MODE, int NS = 4>       // (an eight-slot ring, 128 instead of 96 KB of LDS, measured no faster in round 3)
 int launch_convflat(Conv3x3Args& a, hipStream_t s) {
   constexpr int lds = 2 * 4 * 128 * 64 + NS * BN * 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  if (NS == 8) {       // four slots (96 instead of 128 KB of LDS) since round 3: 3.84 against 3.87 ms per G + D step with the
-                       // weight gradients at one workgroup per CU; S2S_FLAT_NS=8: the seven-tap ring
-    static const int ns_env = [] { const char* e = getenv("S2S_FLAT_NS"); return e ? atoi(e) : 4; }();
-    if (ns_env == 4) return launch_convflat<BN, MODE, 4>(a, s);
-  }
   auto kern = convflat_dma16_kernel<BN, MODE, NS>;
   static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
@@ -2244,18 +2237,7 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
       default: break;
     }
   }
-  // weight ring depth: four slots everywhere.  S2S_CONV_NS=8 gives the 64-channel tiles seven taps of DMA lead (80 KB of
-  // LDS, still two workgroups per CU): measured in round 3 on the 256^2 layers, whose taps run at ~46 % of the MFMA rate,
-  // and no faster (250 vs 242 us on 192 -> 64) -- the slab's round trip is not what those taps wait for.
-  static const int ns64 = [] { const char* e = getenv("S2S_CONV_NS"); return e ? atoi(e) : 4; }();
-  if (ns64 == 8)
-    switch (id) {
-      case 1: return launch_dma16<8, 32, 64, 4, 1, 8>(a, s);
-      case 3: return launch_dma16<4, 32, 64, 2, 2, 8>(a, s);
-      case 5: return launch_dma16<16, 16, 64, 4, 1, 8>(a, s);
-      case 7: return launch_dma16<8, 16, 64, 2, 2, 8>(a, s);
-      default: break;
-    }
+  // weight ring depth: four slots everywhere (eight gave the 64-channel tiles nothing: 250 vs 242 us on 192 -> 64, round 3)
   switch (id) {
     case 0: return launch_dma16<8, 32, 128, 2, 2, 4>(a, s);
     case 1: return launch_dma16<8, 32, 64, 4, 1, 4>(a, s);
@@ -2373,8 +2355,6 @@ extern "C" int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, i
   { static const int use_dma = [] { const char* e = getenv("S2S_CONV_DMA"); return e ? atoi(e) : 16; }();
     if (use_dma != 16) return legacy; }
 #endif
-  static const int carry = [] { const char* e = getenv("S2S_CONV_STAT_CARRY"); return e ? atoi(e) : 1; }();
-  if (!carry) return legacy;
   Conv3x3Args a{};
   static const float one = 1.f;
   conv3x3_fill_args(a, ld0, c0, ld1, c1, has_bias ? &one : nullptr, B, H, W, Cout);

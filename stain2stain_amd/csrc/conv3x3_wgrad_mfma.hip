@@ -244,30 +244,23 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// NT = 9: a workgroup accumulates all nine taps (one dY fragment feeds nine MFMAs).
-// NT = 3: the three kh rows go to three workgroups (blockIdx.z = split*3 + kh) that each accumulate the three kw
-//         taps of their row and stage only the TH halo rows they need.  Three times the workgroups for the same
-//         number of pixel splits, i.e. a third of the partial-slab traffic for the same machine fill -- used for
-//         the layers with few (co,ci) tiles, where the slabs, not the MFMAs, set the time.
-// KHW (with NT = 3): the three kh rows go to three 4-wave TEAMS of one 12-wave workgroup instead.  The teams share
-//         one staged dY tile and one full halo, a wave holds 48 accumulators (three waves per SIMD), and the machine is
-//         filled by 256 workgroups instead of 512 -- half the pixel splits, i.e. half the partial-slab bytes written at
-//         the end of the kernel (when every workgroup stores at once and the MFMAs idle) and read back by the reduce.
-template <int TH, int TW, int NT, bool KHW = false>
-__global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
+// A workgroup accumulates all nine taps (one dY fragment feeds nine MFMAs).  (Rounds 2-3 also built the kernel rows over
+// three workgroups, over the three 4-wave teams of a 12-wave workgroup, a two-team pixel split and a 16x16x32-MFMA form:
+// all parity-green, all 8-18 % slower -- DESIGN.md section 3.2 -- and deleted in round 4.)
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgradArgs a) {
   using T = bf16_t;
-  static_assert(!KHW || NT == 3, "teams own one kernel row each");
-  constexpr int NW = KHW ? 12 : 4;
+  constexpr int NW = 4, NT = 9;
   constexpr int NPX = TH * TW;                             // 128
-  constexpr int HW_ = TW + 2, HR = (NT == 9 || KHW) ? TH + 2 : TH, HALO = HR * HW_;
-  constexpr int XROWS = (HALO + 31) / 32 * 32;             // 192 / 160 (whole DMA groups, 4 waves x 2 halves)
+  constexpr int HW_ = TW + 2, HR = TH + 2, HALO = HR * HW_;
+  constexpr int XROWS = (HALO + 31) / 32 * 32;             // 192 (whole DMA groups, 4 waves x 2 halves)
   constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
-  constexpr int DYGRP = 2 * NPX / 16, XGRP = 2 * XROWS / 16;   // 16-row DMA groups per tile (16 / 24 or 20)
-  constexpr int DYG = (DYGRP + NW - 1) / NW;               // dY DMA instr per wave (4; 2 with twelve waves)
-  constexpr int XG = (XGRP + NW - 1) / NW;                 // halo DMA instr per wave (6 / 5; 2)
+  constexpr int DYGRP = 2 * NPX / 16, XGRP = 2 * XROWS / 16;   // 16-row DMA groups per tile (16 / 24)
+  constexpr int DYG = DYGRP / NW;                          // dY DMA instr per wave (4)
+  constexpr int XG = XGRP / NW;                            // halo DMA instr per wave (6)
   constexpr int BUF = DY_BYTES + X_BYTES;
   constexpr int KSTEPS = NPX / 16;
-  static_assert(KHW || (DYGRP % 4 == 0 && XGRP % 4 == 0), "DMA groups split evenly over 4 waves");
+  static_assert(DYGRP % 4 == 0 && XGRP % 4 == 0, "DMA groups split evenly over 4 waves");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
   const T* __restrict__ dy = static_cast<const T*>(a.dy);
@@ -287,9 +280,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
   const int ci0 = bx * 64, co0 = by * 64;
   const int cin = a.c0 + a.c1;
   const int drow = lane >> 2, dslot = lane & 3;
-  const int kh0 = (NT == 9) ? 0 : KHW ? (wave >> 2) : (int)(bz % 3);
-  const int khx = KHW ? 0 : kh0;                            // first kernel row of the staged halo
-  const int zsplit = (NT == 9 || KHW) ? (int)bz : (int)(bz / 3);
+  const int zsplit = (int)bz;
 
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int frag_off = ((g >> 1) * 8 + q) * 64 + ((g & 1) * 16 + p * 4) * 2;
@@ -328,7 +319,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
       if (ci < a.c0) { x_ptr[j] = x0 + ci; x_ld[j] = a.ld0; }
       else if (ci < cin) { x_ptr[j] = x1 + (ci - a.c0); x_ld[j] = a.ld1; }
     }
-    x_off[j] = ((x_hy[j] - 1 + khx) * a.W + (x_hx[j] - 1)) * x_ld[j];
+    x_off[j] = ((x_hy[j] - 1) * a.W + (x_hx[j] - 1)) * x_ld[j];
   }
 
   auto dma_tile = [&](int tile, int buf) {
@@ -343,20 +334,17 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
     if (interior) {
 #pragma unroll
       for (int j = 0; j < DYG; ++j) {
-        if (KHW && wave + NW * j >= DYGRP) break;                       // wave-uniform
         const void* src = dy_ok[j] ? (const void*)(dy + pixbase * a.lddy + dy_off[j]) : (const void*)g_wgrad_zero_page;
         dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + NW * j) * 1024));
       }
 #pragma unroll
       for (int j = 0; j < XG; ++j) {
-        if (KHW && wave + NW * j >= XGRP) break;
         const void* src = x_ptr[j] ? (const void*)(x_ptr[j] + pixbase * x_ld[j] + x_off[j]) : (const void*)g_wgrad_zero_page;
         dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + NW * j) * 1024));
       }
     } else {
 #pragma unroll
       for (int j = 0; j < DYG; ++j) {
-        if (KHW && wave + NW * j >= DYGRP) break;
         const int gy = y0 + dy_py[j], gx = xs + dy_px[j];
         const void* src = g_wgrad_zero_page;
         if (gy < a.H && gx < a.W && dy_ok[j]) src = dy + pixbase * a.lddy + dy_off[j];
@@ -364,8 +352,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
       }
 #pragma unroll
       for (int j = 0; j < XG; ++j) {
-        if (KHW && wave + NW * j >= XGRP) break;
-        const int gy = y0 - 1 + khx + x_hy[j], gx = xs - 1 + x_hx[j];
+        const int gy = y0 - 1 + x_hy[j], gx = xs - 1 + x_hx[j];
         const void* src = g_wgrad_zero_page;
         if (x_ptr[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = x_ptr[j] + pixbase * x_ld[j] + x_off[j];
         dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + NW * j) * 1024));
@@ -381,7 +368,7 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
   for (; tile < a.ntiles; tile += a.S) {
     if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);   // lands during the MFMAs below
     const char* const Ahi = smem + buf * BUF + wco * (NPX * 64) + frag_off;
-    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off + (KHW ? kh0 * (HW_ * 64) : 0);
+    const char* const Bhi = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64) + frag_off;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int m0 = ks * 16;
@@ -406,198 +393,13 @@ __global__ __launch_bounds__(KHW ? 768 : 256, KHW ? 1 : 2) void conv3x3_wgrad_dm
   const int ci = ci0 + wci * 32 + r;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int tap = kh0 * 3 + t;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int co = co0 + wco * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
       if (co < a.Cout && ci < cin)
-        a.part[(((long)zsplit * 9 + tap) * a.Cout + co) * cin + ci] = acc[t][j];
+        a.part[(((long)zsplit * 9 + t) * a.Cout + co) * cin + ci] = acc[t][j];
     }
   }
-}
-
-// The same kernel on v_mfma_f32_16x16x32_bf16 (S2S_WGRAD_MFMA=16).  A k-step is 32 pixels = two rows of the 8 x 16 tile;
-// a wave's 32 x 32 (co, ci) block per tap is four 16 x 16 accumulators.  Operand fragments: lane l holds k = 8 (l >> 4)
-// .. + 7 of row / column l & 15, so the 16-lane group g reads pixel rows 8 g + {0..3} and 8 g + {4..7} of a 16-channel
-// column block with two ds_read_b64_tr_b16.  The two groups of a half-wave (g, g + 1) then read rows EIGHT apart in the
-// same columns, which with 64-byte rows are the same banks: the images are stored with the two 32-byte halves of a row
-// swapped where bit 3 of the row's position is set -- the pixel index for dY, the halo COLUMN for X (rows 8 apart in a
-// k-step are columns hx and hx + 8 of one halo row, whatever the halo pitch) -- by swapping the 16-byte pieces a DMA
-// lane fetches; the read offsets carry the same XOR (lane-constant for dY; three kw x two row-quads for X).
-#ifndef M16_UNROLL
-#define M16_UNROLL 1
-#endif
-template <int TH, int TW>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_m16_kernel(WgradArgs a) {
-  using T = bf16_t;
-  static_assert(TW == 16 && TH % 2 == 0, "a 32-pixel k-step is two 16-pixel tile rows");
-  constexpr int NW = 4, NT = 9;
-  constexpr int NPX = TH * TW;
-  constexpr int HW_ = TW + 2, HR = TH + 2, HALO = HR * HW_;
-  constexpr int XROWS = (HALO + 31) / 32 * 32;
-  constexpr int DY_BYTES = 2 * NPX * 64, X_BYTES = 2 * XROWS * 64;
-  constexpr int DYG = 2 * NPX / 16 / NW, XG = 2 * XROWS / 16 / NW;
-  constexpr int BUF = DY_BYTES + X_BYTES;
-  constexpr int KSTEPS = NPX / 32;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
-  const T* __restrict__ dy = static_cast<const T*>(a.dy);
-  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
-  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave >> 1, wci = wave & 1;
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (a.xcd) {
-    const unsigned L = bx + gridDim.x * (by + gridDim.y * bz), per = gridDim.x * gridDim.y * gridDim.z / 8;
-    unsigned Lq = (L & 7) * per + (L >> 3);
-    bx = Lq % gridDim.x; Lq /= gridDim.x;
-    by = Lq % gridDim.y; bz = Lq / gridDim.y;
-  }
-  const int ci0 = bx * 64, co0 = by * 64;
-  const int cin = a.c0 + a.c1;
-  const int drow = lane >> 2, dslot = lane & 3;
-  const int zsplit = (int)bz;
-
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  // dY fragment (co half h): pixel rows 32 ks + 8 g + q (+ 4), columns 16 h + 4 p; key = bit 3 of the pixel = g & 1
-  int aofs[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) aofs[h] = (8 * g + q) * 64 + ((32 * h + 8 * p) ^ ((g & 1) * 32));
-  // X fragment (ci half h, tap column kw, row quad s): halo row (g >> 1) relative to the k-step's first, halo column
-  // hx = kw + 8 (g & 1) + q + 4 s; key = bit 3 of hx
-  int bofs[3][2];                 // ci half 0; half 1 = the same offset with bit 5 flipped (row offsets are multiples of 64)
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int sq = 0; sq < 2; ++sq) {
-      const int hx = kw + 8 * (g & 1) + q + 4 * sq;
-      bofs[kw][sq] = ((g >> 1) * HW_ + hx) * 64 + ((8 * p) ^ (((hx >> 3) & 1) * 32));
-    }
-
-  f32x4 acc[NT][2][2];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[t][i][j][k] = 0.f;
-
-  int dy_off[DYG], dy_yx[DYG];            // dy_yx = (row << 8) | column inside the tile; dy_off < 0: channel out of range
-
-#pragma unroll
-  for (int j = 0; j < DYG; ++j) {
-    const int grp = wave + NW * j;
-    const int half = grp / (NPX / 16), px = (grp % (NPX / 16)) * 16 + drow;
-    const int co = co0 + half * 32 + (dslot ^ (((px >> 3) & 1) << 1)) * 8;      // 32-byte halves swapped where bit 3 is set
-    const int ty_ = px / TW, tx_ = px - ty_ * TW;
-    dy_yx[j] = (ty_ << 8) | tx_;
-    dy_off[j] = co < a.Cout ? (ty_ * a.W + tx_) * a.lddy + co : -1;
-  }
-  const T* x_ptr[XG];
-  int x_off[XG], x_ld[XG], x_yx[XG];
-#pragma unroll
-  for (int j = 0; j < XG; ++j) {
-    const int grp = wave + NW * j;
-    const int half = grp / (XROWS / 16), px = (grp % (XROWS / 16)) * 16 + drow;
-    const int hy_ = px / HW_, hx_ = px - hy_ * HW_;
-    x_yx[j] = (hy_ << 8) | hx_;
-    const int ci = ci0 + half * 32 + (dslot ^ (((hx_ >> 3) & 1) << 1)) * 8;
-    x_ptr[j] = nullptr; x_ld[j] = 0;
-    if (px < HALO) {
-      if (ci < a.c0) { x_ptr[j] = x0 + ci; x_ld[j] = a.ld0; }
-      else if (ci < cin) { x_ptr[j] = x1 + (ci - a.c0); x_ld[j] = a.ld1; }
-    }
-    x_off[j] = ((hy_ - 1) * a.W + (hx_ - 1)) * x_ld[j];
-  }
-
-  auto dma_tile = [&](int tile, int buf) {
-    int bt = tile;
-    const int tx = bt % a.tilesX; bt /= a.tilesX;
-    const int ty = bt % a.tilesY;
-    const int img = bt / a.tilesY;
-    const int y0 = ty * TH, xs = tx * TW;
-    const long pixbase = (long)(img * a.H + y0) * a.W + xs;
-    const bool interior = y0 >= 1 && y0 + TH + 1 <= a.H && xs >= 1 && xs + TW + 1 <= a.W;
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + buf * BUF;
-#pragma unroll
-    for (int j = 0; j < DYG; ++j) {
-      const int gy = y0 + (dy_yx[j] >> 8), gx = xs + (dy_yx[j] & 255);
-      const void* src = g_wgrad_zero_page;
-      if (dy_off[j] >= 0 && (interior || (gy < a.H && gx < a.W))) src = dy + pixbase * a.lddy + dy_off[j];
-      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + (wave + NW * j) * 1024));
-    }
-#pragma unroll
-    for (int j = 0; j < XG; ++j) {
-      const int gy = y0 - 1 + (x_yx[j] >> 8), gx = xs - 1 + (x_yx[j] & 255);
-      const void* src = g_wgrad_zero_page;
-      if (x_ptr[j] && (interior || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W))) src = x_ptr[j] + pixbase * x_ld[j] + x_off[j];
-      dma16_asm(src, __builtin_amdgcn_readfirstlane(base + DY_BYTES + (wave + NW * j) * 1024));
-    }
-  };
-
-  auto frag = [](const char* p0, const char* p1) {
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
-    bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { r[i] = l4[i]; r[4 + i] = h4[i]; }
-    return r;
-  };
-
-  int tile = zsplit;
-  int buf = 0;
-  if (tile < a.ntiles) dma_tile(tile, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (; tile < a.ntiles; tile += a.S) {
-    if (tile + a.S < a.ntiles) dma_tile(tile + a.S, buf ^ 1);
-    const char* const Ab = smem + buf * BUF + wco * (NPX * 64);
-    const char* const Bb = smem + buf * BUF + DY_BYTES + wci * (XROWS * 64);
-#pragma unroll M16_UNROLL
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      bf16x8 af[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) af[h] = frag(Ab + ks * 32 * 64 + aofs[h], Ab + ks * 32 * 64 + aofs[h] + 4 * 64);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int kh = t / 3, kw = t % 3;
-        const char* const rb = Bb + ((2 * ks + kh) * HW_) * 64;
-        bf16x8 bf[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) bf[h] = frag(rb + (bofs[kw][0] ^ (32 * h)), rb + (bofs[kw][1] ^ (32 * h)));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[t][i][j], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    buf ^= 1;
-  }
-
-  // accumulator (i, j): rows co = 16 i + 4 g + r (r < 4), column ci = 16 j + (lane & 15)
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ci = ci0 + wci * 32 + j * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + wco * 32 + i * 16 + 4 * g + r;
-          if (co < a.Cout && ci < cin)
-            a.part[(((long)zsplit * 9 + t) * a.Cout + co) * cin + ci] = acc[t][i][j][r];
-        }
-      }
 }
 
 // grad[co][ci][tap] (+)= sum_z part[z][tap][co][ci].  A workgroup owns 64 consecutive (co,ci) pairs; its ZG
@@ -652,35 +454,16 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   return S2S_OK;
 }
 
-template <int TH, int TW, int NT, bool KHW = false>
-int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
-  constexpr int XROWS = (((NT == 9 || KHW) ? TH + 2 : TH) * (TW + 2) + 31) / 32 * 32;
-  constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
-  a.tilesY = cdiv(a.H, TH);
-  a.tilesX = cdiv(a.W, TW);
-  a.ntiles = a.B * a.tilesY * a.tilesX;
-  if (a.S > a.ntiles) return S2S_ERR_SHAPE;
-  auto kern = conv3x3_wgrad_dma_kernel<TH, TW, NT, KHW>;
-  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
-  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
-  dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S * ((NT == 9 || KHW) ? 1 : 3));
-  static const int xcd_aware = [] { const char* e = getenv("S2S_WGRAD_XCD"); return e ? atoi(e) : 1; }();
-  a.xcd = xcd_aware && ((long)grid.x * grid.y * grid.z) % 8 == 0;
-  hipLaunchKernelGGL(kern, grid, dim3(KHW ? 768 : 256), lds, s, a);
-  S2S_LAUNCH_CHECK();
-  return S2S_OK;
-}
-
 template <int TH, int TW>
-int launch_wgrad_dma_m16(WgradArgs& a, hipStream_t s) {
+int launch_wgrad_dma(WgradArgs& a, hipStream_t s) {
   constexpr int XROWS = ((TH + 2) * (TW + 2) + 31) / 32 * 32;
   constexpr int lds = 2 * (2 * TH * TW * 64 + 2 * XROWS * 64);
   a.tilesY = cdiv(a.H, TH);
   a.tilesX = cdiv(a.W, TW);
   a.ntiles = a.B * a.tilesY * a.tilesX;
   if (a.S > a.ntiles) return S2S_ERR_SHAPE;
-  auto kern = conv3x3_wgrad_dma_m16_kernel<TH, TW>;
-  static unsigned long long attr_devs = 0;
+  auto kern = conv3x3_wgrad_dma_kernel<TH, TW>;
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
   if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr_devs)) return rc;
   dim3 grid(cdiv(a.c0 + a.c1, 64), cdiv(a.Cout, 64), a.S);
   static const int xcd_aware = [] { const char* e = getenv("S2S_WGRAD_XCD"); return e ? atoi(e) : 1; }();
@@ -688,17 +471,6 @@ int launch_wgrad_dma_m16(WgradArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
-}
-
-// how the nine taps are spread (bf16 DMA kernel): 0 = nine per wave, 1 = the kh rows over three workgroups, 2 = the kh
-// rows over the three 4-wave teams of a 12-wave workgroup
-inline int wgrad_kh_split(int dtype, int Cin, int Cout) {
-  static const int mode = [] { const char* e = getenv("S2S_WGRAD_KH"); return e ? atoi(e) : -1; }();
-  if (dtype != S2S_BF16) return 0;
-  static const int mfma = [] { const char* e = getenv("S2S_WGRAD_MFMA"); return e ? atoi(e) : 32; }();
-  if (mfma == 16) return 16;      // nine taps per wave on 16x16x32 MFMAs (conv3x3_wgrad_dma_m16_kernel)
-  if (mode >= 0) return mode;
-  return 0;   // 1 re-measured after the reduce kernel was widened: nine taps per workgroup win by 8% even at 64->64
 }
 
 // =========================================================================================================
@@ -1422,8 +1194,7 @@ int wgrad_ntiles(int B, int H, int W) { return B * cdiv(H, 8) * cdiv(W, 16); }
 extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return S2S_ERR_SHAPE;
   const int nt = wgrad_ntiles(B, H, W);
-  const int khm = wgrad_kh_split(dtype, Cin, Cout);
-  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64) * (khm == 1 ? 3 : 1);
+  const int mn = cdiv(Cin, 64) * cdiv(Cout, 64);
   static const int target_env = [] { const char* e = getenv("S2S_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
   // ONE workgroup per CU (256; round 3).  Alone, the kernel is 7 % faster with two per CU (1078 against 1003 TFLOP/s), but
   // a pair takes every vector register of its CU, and this kernel runs on the side stream UNDER the bandwidth-bound
@@ -1433,13 +1204,11 @@ extern "C" int s2s_conv3x3_wgrad_splits(int dtype, int B, int H, int W, int Cin,
   // 384: 7.58-7.64, 256: 7.45-7.52, 224: 7.49, 192: 7.59, 128: 7.93.  S2S_WGRAD_BLOCKS=512 restores two per CU.
   const int target = target_env ? target_env : 256;   // (384 / 512 for the concat-input layers alone: 7.48 / 7.52 against 7.45 ms)
   // every split costs a |dW| x 4 B partial slab; the cap only matters for targets above 320
-  static const int cap_env = [] { const char* e = getenv("S2S_WGRAD_CAP"); return e ? atoi(e) : 0; }();
-  const int cap = cap_env ? cap_env : (mn == 1 ? 512 : 320);   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
+  const int cap = mn == 1 ? 512 : 320;   // 64->64, 256x256, batch 16, with the 16-wave reduce: 400 -> 110 us, 512 -> 103 us
   int s = target / mn;
   // (a layer whose (co, ci) tiles alone are 3/4 of the target -- 1536 -> 512: 192 tiles -- would leave a quarter of the CUs
   //  without a workgroup: one more split)
-  static const int fill = [] { const char* e = getenv("S2S_WGRAD_FILL"); return e ? atoi(e) : 1; }();
-  if (fill && s >= 1 && (long)s * mn < (long)target * 7 / 8 && (long)(s + 1) * mn <= 2L * target) s += 1;
+  if (target_env == 0 && s >= 1 && (long)s * mn < (long)target * 7 / 8 && (long)(s + 1) * mn <= 2L * target) s += 1;
   if (s > cap) s = cap;
   if (s > nt) s = nt;
   if (s < 1) s = 1;
@@ -1463,17 +1232,9 @@ extern "C" int s2s_conv3x3_wgrad_phase(int dtype, const void* dy, int lddy, int 
   a.S = s2s_conv3x3_wgrad_splits(dtype, B, H, W, c0 + c1, Cout);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = S2S_OK;
-  static const int use_dma = [] { const char* e = getenv("S2S_WGRAD_DMA"); return e ? atoi(e) : 1; }();
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
   if (!(phases & 1)) { if (a.S > wgrad_ntiles(B, H, W)) return S2S_ERR_SHAPE; }
-  else if (dtype == S2S_BF16 && use_dma)
-    switch (wgrad_kh_split(dtype, c0 + c1, Cout)) {
-      case 16: rc = launch_wgrad_dma_m16<8, 16>(a, s); break;
-      case 1: rc = launch_wgrad_dma<8, 16, 3>(a, s); break;
-      case 2: rc = launch_wgrad_dma<8, 16, 3, true>(a, s); break;
-      default: rc = launch_wgrad_dma<8, 16, 9>(a, s);
-    }
-  else if (dtype == S2S_BF16) rc = launch_wgrad<bf16_t, 8, 16>(a, s);
+  else if (dtype == S2S_BF16) rc = launch_wgrad_dma<8, 16>(a, s);
   else rc = launch_wgrad<float, 8, 16>(a, s);
   if (rc != S2S_OK || !(phases & 2)) return rc;
   const long n = (long)Cout * (c0 + c1);

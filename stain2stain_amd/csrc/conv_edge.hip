@@ -713,7 +713,7 @@ extern "C" int s2s_stem_conv3x3_fwd(int dtype, const float* x_nchw, const float*
 extern "C" int s2s_stem_wgrad_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return S2S_ERR_SHAPE;
   const int nt = B * cdiv(H, 16) * cdiv(W, 16);
-  static const int cap = [] { const char* e = getenv("S2S_STEM_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // 2 per CU: 98 us vs 126 us at 256
+  constexpr int cap = 512;   // 2 per CU: 98 us vs 126 us at 256
   return nt < cap ? nt : cap;
 }
 
@@ -845,7 +845,6 @@ extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const floa
   hipStream_t s = (hipStream_t)stream;
   const float coef = (float)(2.0 * (double)grad_scale / count);
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
-  static const int lanes_off = [] { const char* e = getenv("S2S_HEAD_LANES"); return e && atoi(e) == 0; }();
   const int pcb = C / 8;
   bool done = false;
 #define S2S_HL(TT, PP)                                                                                              \
@@ -858,9 +857,7 @@ extern "C" int s2s_head_loss_fused(int dtype, const void* x, int ldx, const floa
     case 8: { S2S_HL(TT, 8) } break;  case 16: { S2S_HL(TT, 16) } break; case 32: { S2S_HL(TT, 32) } break;  \
     case 64: { S2S_HL(TT, 64) } break; default: break;                                                  \
   }
-  if (!lanes_off) {
-    if (dtype == S2S_BF16) { S2S_HL_T(bf16_t) } else { S2S_HL_T(float) }
-  }
+  if (dtype == S2S_BF16) { S2S_HL_T(bf16_t) } else { S2S_HL_T(float) }
 #undef S2S_HL_T
 #undef S2S_HL
   if (!done) {

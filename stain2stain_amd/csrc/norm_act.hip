@@ -704,13 +704,11 @@ extern "C" int s2s_bn_relu_bwd_phase(int dtype, const void* g1, int ldg1, const 
   // Gradient of the conv bias that feeds a train-mode BatchNorm: sum over pixels of dx, which the BN backward
   // formula makes identically zero (sum dz - N c1 - c2 sum xhat, with c1 = sum dz / N and sum xhat = 0).  The
   // reference's autograd sums it anyway and gets rounding noise of either sign (|.| ~ 1e-9); by default we write the
-  // exact value and skip the partial sums and their two reduction launches per layer.  S2S_BN_DBIAS_SUM=1 restores
-  // the summed form (tests compare the two).
-  static const int dbias_sum = [] { const char* e = getenv("S2S_BN_DBIAS_SUM"); return e ? atoi(e) : 0; }();
-  float* const dbias_zero = (dbias_conv && !dbias_sum && !accumulate) ? dbias_conv : nullptr;
-  if (dbias_conv && !dbias_sum) dbias_conv = nullptr;
+  // exact value and skip the partial sums and their two reduction launches per layer.
+  float* const dbias_zero = (dbias_conv && !accumulate) ? dbias_conv : nullptr;
+  dbias_conv = nullptr;
   dim3 grid(cdiv(C / 8, host_pcb(C)), nb);
-  static const int bn_rev = [] { const char* e = getenv("S2S_BN_REV"); return e ? atoi(e) : 1; }();
+  constexpr int bn_rev = 1;      // the flat apply pass walks the tensor back to front: it starts on what the reduction read last
 #define S2S_BN_BWD(TT)                                                                                             \
   if (!(phases & 1)) {                                                                                             \
   } else if (gp) {                                                                                                 \

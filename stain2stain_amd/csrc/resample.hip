@@ -286,8 +286,7 @@ extern "C" int s2s_upsample2x_bilinear_ac_bwd(int dtype, const void* dy, int ldd
   if (total >= (1L << 31) - (1L << 22)) return S2S_ERR_SHAPE;   // 32-bit element index in the kernel
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ew_grid(total));
-  static const int windowed = [] { const char* e = getenv("S2S_UP_BWD_WIN"); return e ? atoi(e) : 1; }();
-  const bool win = windowed && Hin > 3 && Win > 3;       // at most five contributing rows / columns per source pixel
+  const bool win = Hin > 3 && Win > 3;       // at most five contributing rows / columns per source pixel (else the branching gather)
   if (dtype != S2S_BF16 && dtype != S2S_F32) return S2S_ERR_DTYPE;
 #define S2S_UPB(KERN, TT)                                                                                            \
   hipLaunchKernelGGL(KERN<TT>, grid, dim3(256), 0, s, (const TT*)dy, lddy, (TT*)dx, lddx, B, Hin, Win, Hout, Wout,   \
