@@ -1094,6 +1094,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma16_kernel(Conv3x3Args a) {
       __builtin_amdgcn_sched_barrier(0);
       if (!S2S_ABL(a.dbg & 256)) wait_vm<(NS - 2) * BG + (tap <= NS - 3 ? HG : 0)>();
       if (!S2S_ABL(a.dbg & 32)) __builtin_amdgcn_s_barrier();
+#ifdef S2S_ABLATE
+      // Timing only (S2S_CONV_DBG=1024): what a consumer-side BatchNorm + ReLU would cost this loop.
+      // The input arrives by LDS-DMA, so the affine + ReLU has to be a read-modify-write pass over the next chunk's halo
+      // image in LDS (it has landed by tap 2) plus a barrier, once per chunk.  scale / shift / floor are run-time values
+      // that leave the data as it is (a real ReLU would zero half the operands and let the clock rise).
+      if ((a.dbg & 1024) && tap == 8) {
+        char* nb = ldsA + ((c + 1) & 1) * A_BYTES;
+        const float sc = 1.0f + a.act_slope, sh = a.act_slope, fl = a.act_slope - 3.0e38f;
+#pragma unroll
+        for (int j = 0; j < HG; ++j) {
+          bf16x8* p8 = reinterpret_cast<bf16x8*>(nb + (tid + 256 * j) * 16);
+          bf16x8 v = *p8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (bf16_t)fmaxf(fmaf((float)v[k], sc, sh), fl);
+          *p8 = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+#endif
     });
   }
   // the epilogue's per-channel bias: fetched here so that the load latency hides behind the last nine taps

@@ -186,7 +186,9 @@ def repack_stale(cbs: Sequence[ConvBN], dtype: torch.dtype) -> None:
     if len(stale) < 2:
         return
     bufs = [cb.ensure_buffers(dtype) for cb in stale]
-    key = (dtype,) + tuple((cb.conv.weight.data_ptr(), b[0].data_ptr()) for cb, b in zip(stale, bufs))
+    # (every field of a descriptor row is part of the key: the allocator re-uses addresses across modules)
+    key = (dtype,) + tuple((cb.conv.weight.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), cb.cout, cb.cin)
+                           for cb, b in zip(stale, bufs))
     hit = _REPACK_DESC.get(key)
     if hit is None:
         rows, start = [], 0

@@ -68,7 +68,8 @@ class FusedAdam(torch.optim.Optimizer):
                 dev = items[0][0].device
                 # the descriptor table is rebuilt (one small pinned-memory copy) only when a pointer moved: with
                 # zero_grad(set_to_none=True) the caching allocator hands the same gradient blocks out step after step
-                key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr()) for p, g, st in items)
+                key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                            for p, g, st in items)
                 hit = self._desc_cache.get(gi)
                 if hit is None or hit[0] != key:
                     rows, start = [], 0
