@@ -105,18 +105,44 @@ def _L():
 # that still read it.  (Keyed by (device, tag) alone, a larger launch on the side stream could retire a block the compute
 # stream had allocated while the side stream's previous launch was still reading its slabs: ADVICE r2.)
 _WORKSPACE = {}
+# A captured training step bakes the buffer's address into its hipGraph, and a replay is not ordered against a later
+# host-side replacement of the buffer: with one process-global buffer per (device, tag, stream), a second, wider trainer
+# on the same stream would grow it -- returning the old block to the allocator -- while the first trainer's graph still
+# writes its slabs there on every replay.  So the buffers belong to an OWNER: a trainer brackets its step
+# with ``workspace_owner(self)``; it warms its own buffers in its eager first step, its capture finds them (no
+# allocation inside the capture), nobody else can replace them, and they are dropped with the trainer
+# (``release_workspaces``).  Launches outside any trainer (the module path, tests) share the anonymous owner.
+_WS_OWNER = 0
+
+
+class workspace_owner:
+    def __init__(self, owner):
+        self.key = id(owner)
+
+    def __enter__(self):
+        global _WS_OWNER
+        self.prev, _WS_OWNER = _WS_OWNER, self.key
+        return self
+
+    def __exit__(self, *exc):
+        global _WS_OWNER
+        _WS_OWNER = self.prev
+        return False
+
+
+def release_workspaces(owner) -> None:
+    k = id(owner)
+    for key in [key for key in _WORKSPACE if key[3] == k]:
+        del _WORKSPACE[key]
 
 
 def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
-    # A step that is being CAPTURED bakes the buffer's address into the graph, and a replay is not ordered against a later
-    # host-side replacement of the process-global buffer (a second, wider trainer on the same stream growing it would
-    # return the old block to the allocator while the graph still writes its slabs there: ADVICE r3).  So a capture gets
-    # an allocation of its own, which lives in the graph's private memory pool for as long as the graph does.
-    if torch.cuda.is_current_stream_capturing():
-        return torch.empty((max(numel, 1),), dtype=torch.float32, device=device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream(), _WS_OWNER)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < numel:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("stain2stain_amd: a captured step needs a workspace its eager warm-up step did not allocate "
+                               f"({tag}, {numel} floats): shapes must not change between the warm-up and the capture")
         buf = torch.empty((max(numel, 1 << 20),), dtype=torch.float32, device=device)
         _WORKSPACE[key] = buf
     return buf[:numel]

@@ -611,9 +611,10 @@ class Pix2PixTrainer:
         """One training step on this rank's shard of the global batch (the reference shards a batch as
         ``batch_size // world_size`` per rank, src/data/paired_data_module.py:273-278); returns the ``losses`` vector
         (rank means when ``sync_loss``), still on the device."""
-        if self.graph and ops._PROFILE is None:
-            return self._step_graphed(src, tgt)
-        return self._step_body(src, tgt, None)
+        with ops.workspace_owner(self):          # split-K / weight-gradient slabs belong to this trainer (ops._workspace)
+            if self.graph and ops._PROFILE is None:
+                return self._step_graphed(src, tgt)
+            return self._step_body(src, tgt, None)
 
     def _step_body(self, src, tgt, hyper_dev) -> torch.Tensor:
         losses, _ = self.losses_and_grads(src, tgt, update=True, hyper_dev=hyper_dev)
@@ -656,6 +657,7 @@ class Pix2PixTrainer:
     def close(self) -> None:
         """Drop the captured graph, its static buffers and the pinned Adam-scalar ring now (see CFMTrainer.close)."""
         self._captured, self._warm_key, self._hyper = None, None, None
+        ops.release_workspaces(self)
 
     def __del__(self):
         try:

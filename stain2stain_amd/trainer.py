@@ -298,12 +298,13 @@ class CFMTrainer:
 
     def step(self, x0: torch.Tensor, x1: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One training step on this rank's shard of the global batch; returns the (rank-mean) loss."""
-        if self.graph and ops._PROFILE is None:
-            return self._step_graphed(x0, x1, t)
-        self.step_count += 1
-        loss = self._step_body(x0, x1, t, None)
-        engine.mutation_epoch[0] += 1
-        return loss
+        with ops.workspace_owner(self):          # split-K / weight-gradient slabs belong to this trainer (ops._workspace)
+            if self.graph and ops._PROFILE is None:
+                return self._step_graphed(x0, x1, t)
+            self.step_count += 1
+            loss = self._step_body(x0, x1, t, None)
+            engine.mutation_epoch[0] += 1
+            return loss
 
     def _step_body(self, x0, x1, t, hyper_dev) -> torch.Tensor:
         loss, _ = self.forward_backward(x0, x1, t, want_v=False)
@@ -365,6 +366,7 @@ class CFMTrainer:
         fully alive (a captured step sits in a reference cycle with its trainer; left to the cyclic collector it may be
         destroyed during another capture or at interpreter exit, in an order the runtime does not define)."""
         self._captured, self._warm_key, self._hyper = None, None, None
+        ops.release_workspaces(self)
 
     def __del__(self):
         try:

@@ -25,9 +25,22 @@ def pytest_collection_modifyitems(config, items):
 
 
 # Captured hipGraphs are released by their owners (CFMTrainer.close / Pix2PixTrainer.close / GraphedVelocity.close, also
-# called from __del__): the tests that capture call close() themselves.  Round 3 had a per-module gc.collect() fixture and
-# a collect + synchronize at session end here instead, added after one multi-file run died at exit behind its last passing
-# test; that run's log was not kept, so which destructor faulted was never established.
+# called from __del__) and the tests that capture call close() themselves.  The module-boundary collection below stays as
+# a second line: trainers sit in reference cycles (trainer <-> optimiser handle), so WHEN an abandoned one is finalised is
+# the cyclic collector's choice, and a run of this suite without the fixture aborted once inside a graph test (round 4,
+# gpurun_out/r04n/tests.log; round 3 lost a run at interpreter exit the same way and kept no log).  DESIGN.md section 3.7.
+@pytest.fixture(autouse=True, scope="module")
+def _collect_between_modules():
+    yield
+    import gc
+    gc.collect()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import gc
+    gc.collect()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
 
 
 def load_golden(name):
