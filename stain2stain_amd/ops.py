@@ -109,8 +109,7 @@ _WORKSPACE = {}
 # host-side replacement of the buffer: with one process-global buffer per (device, tag, stream), a second, wider trainer
 # on the same stream would grow it -- returning the old block to the allocator -- while the first trainer's graph still
 # writes its slabs there on every replay.  So the buffers belong to an OWNER: a trainer brackets its step
-# with ``workspace_owner(self)``; it warms its own buffers in its eager first step, its capture finds them (no
-# allocation inside the capture), nobody else can replace them, and they are dropped with the trainer
+# with ``workspace_owner(self)``: nobody else can replace its buffers, and they are dropped with the trainer
 # (``release_workspaces``).  Launches outside any trainer (the module path, tests) share the anonymous owner.
 _WS_OWNER = 0
 
@@ -140,9 +139,9 @@ def _workspace(device: torch.device, numel: int, tag: str) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream(), _WS_OWNER)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < numel:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("stain2stain_amd: a captured step needs a workspace its eager warm-up step did not allocate "
-                               f"({tag}, {numel} floats): shapes must not change between the warm-up and the capture")
+        # (inside a capture this happens for the capture stream only -- torch.cuda.graph captures on a stream of its own,
+        #  the side stream's buffers exist since the eager warm-up step -- and the buffer, taken from the graph's private
+        #  pool, stays referenced here until its owner releases it)
         buf = torch.empty((max(numel, 1 << 20),), dtype=torch.float32, device=device)
         _WORKSPACE[key] = buf
     return buf[:numel]
