@@ -57,6 +57,7 @@ struct SmallArgs {
   int Cout;                   // output channels of the launch (gridDim.y * 16)
   int SG;                     // samples per workgroup (SG * rows per sample <= 16 * NB)
   int nchunk;                 // Cin / 32
+  int SP;                     // LDSX: LDS rows from one sample to the next
   int nx, ny;                 // tiles: sample groups x 16-channel tiles (the grid is their product, see the kernel)
   int lgntx;
   int t0y, nty, t0x, ntx;     // live taps: MODE 1 kernel rows t0y .. t0y + nty - 1 (of 4), columns likewise;
@@ -74,24 +75,38 @@ struct SmallArgs {
   int bwd_c0;                 // epi 2: first channel that belongs to the normed tensor (a multiple of 16)
 };
 
+typedef __attribute__((address_space(3))) void sm_lds_void_t;
+typedef __attribute__((address_space(1))) const void sm_gbl_void_t;
+
 // One (sample group, 16 output channels) tile.  NB = 16-row pixel blocks per accumulator group; MODE 2 has four groups
 // (the sub-pixel phases), MODE 1 one.
-template <int MODE, int NB>
+//
+// LDSX: the input of the workgroup's samples is staged ONCE in LDS (LDS-DMA, whole pixel rows of Cin x 2 bytes, one
+// barrier) and the pixel fragments are ds_read_b128s of it; only the weights stream from L2.  Without it every tap
+// re-reads its im2col'd pixels through L1 / L2 -- 2-4 x the weight bytes on the 4x4 / 8x8 maps, and a CU takes in no more
+// than ~70 GB/s whatever the loop does (measured: d5 forward 20.6 us, u2 36 us, both at that rate).  LDS image: row
+// rho(pixel) x pitch, pitch = Cin * 2 + 16 (the pad turns consecutive rows into consecutive 16-byte bank slots); rho
+// orders a sample's pixels so that the sixteen rows of a fragment are (nearly) consecutive for every tap -- mode 1
+// (stride 2: a tap reads pixels of ONE parity class) parity-major, (iy & 1, ix & 1) then (iy >> 1, ix >> 1); mode 2
+// row-major -- and samples are SP rows apart with SP = Pin + P when a block holds several samples (P < 16), so that
+// their rows do not meet in a bank either.  Padding pixels read a row of zeros.
+template <int MODE, int NB, bool LDSX>
 __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   constexpr int NW = 8, NG = MODE == 2 ? 4 : 1, D = 4, NQ = NG * NB;
-  __shared__ __attribute__((aligned(16))) float part[NW * NB * 256];   // [wave][block][pixel][channel]
-  __shared__ __attribute__((aligned(16))) float val[NQ * 256];         // reduced tile [q][pixel][channel]
-  __shared__ __attribute__((aligned(16))) float xh[NQ * 256];          // epi 2: normalised activations
-  __shared__ float fin[2][16][16];                                     // per (local sample, channel)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // epilogue arrays (alias the staged input, behind a barrier)
+  float* const part = reinterpret_cast<float*>(smem);                  // [wave][block][pixel][channel]
+  float* const val = part + NW * NB * 256;                             // reduced tile [q][pixel][channel]
+  float* const xh = val + NQ * 256;                                    // epi 2: normalised activations
+  float (*const fin)[16][16] = reinterpret_cast<float (*)[16][16]>(xh + NQ * 256);   // per (local sample, channel)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cl = lane & 15, kp = lane >> 4;
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.  With
   // the plain (sample group, channel tile) order every XCD streamed the layer's WHOLE weight operand (8-17 MB through a
-  // 4 MB L2, eight times over from the Infinity Cache: the launches ran at its ~9 TB/s whatever the loop did); here an
-  // XCD owns ny / 8 channel tiles for all sample groups, so it streams an eighth of the weights and re-reads them from
-  // its own L2.
+  // 4 MB L2, eight times over from the Infinity Cache); here an XCD owns ny / 8 channel tiles for all sample groups, so
+  // it streams an eighth of the weights and re-reads them from its own L2.
   int bx, by;
   {
     const int L = blockIdx.x;
@@ -106,17 +121,40 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   const int n0 = by * 16;
   const int s0 = bx * a.SG;
   const int h = 1 << a.lgh, w = 1 << a.lgw, lgP = a.lgh + a.lgw, P = 1 << lgP;
+  const int Hin = MODE == 1 ? 2 * h : h, Win = MODE == 1 ? 2 * w : w, Pin = Hin * Win;
+  const int pitch = a.Cin * 2 + 16, zrow = a.SG * a.SP;
 
   // this lane's pixel rows: R = mb * 16 + cl -> local sample R >> lgP, pixel R & (P - 1)
-  int rn[NB], ry[NB], rx[NB];
+  int rn[NB], rsl[NB], ry[NB], rx[NB];
   bool rok[NB];
 #pragma unroll
   for (int mb = 0; mb < NB; ++mb) {
     const int R = mb * 16 + cl, sl = R >> lgP, p = R & (P - 1);
+    rsl[mb] = sl;
     rn[mb] = s0 + sl;
     rok[mb] = sl < a.SG && rn[mb] < a.B;
     ry[mb] = p >> a.lgw;
     rx[mb] = p & (w - 1);
+  }
+  if (LDSX) {
+    // stage the samples' input: one LDS-DMA instruction = 1 KiB = (a piece of) one pixel row, wave-uniform destination
+    const int NI = (a.Cin * 2) >> 10;
+    const int nitems = a.SG * Pin * NI;
+    for (int k = wave; k < nitems; k += NW) {
+      const int r = k / NI, piece = k - r * NI;
+      const int sl = r / Pin, pin = r - sl * Pin;
+      const int n = s0 + sl;
+      if (n >= a.B) continue;                                  // (wave-uniform)
+      const int iy = pin / Win, ix = pin - iy * Win;
+      const int rho = MODE == 1 ? sl * a.SP + ((iy & 1) * 2 + (ix & 1)) * (Pin >> 2) + (iy >> 1) * (Win >> 1) + (ix >> 1)
+                                : sl * a.SP + pin;
+      const bf16_t* src = a.x + ((long)(n * Hin + iy) * Win + ix) * a.ldx + piece * 512 + lane * 8;
+      __builtin_amdgcn_global_load_lds((sm_gbl_void_t*)src, (sm_lds_void_t*)(smem + (long)rho * pitch + piece * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < (pitch >> 4); i += 512) {
+      f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(smem + (long)zrow * pitch + i * 16) = z4;
+    }
   }
   // K is cut over the waves by TAP: MODE 1 wave w takes taps w, w + 8, ...; MODE 2 wave w takes phase w & 3 and that
   // phase's taps (w >> 2), (w >> 2) + 2.  Inside a tap the chunk loop only advances pointers.
@@ -125,8 +163,7 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
   const int tfirst = MODE == 2 ? (wave >> 2) : wave, tstep = MODE == 2 ? 2 : NW;
   // A step is a PAIR of 32-channel chunks = 128 B of every pixel row, and the k index of the two MFMAs is permuted so
   // that lane group kp owns 32 contiguous bytes of it (channels 64 p + 16 kp + [0, 8) for the first MFMA, + [8, 16) for
-  // the second): the four lane groups of a row read one whole 128-byte line with two back-to-back 16-byte loads.  (With
-  // one chunk per step every load used half a line and the launch ran at the L2's line rate for half the bytes.)  The
+  // the second): the four lane groups of a row read one whole 128-byte line with two back-to-back 16-byte loads.  The
   // weight fragments follow the same permutation: lane group kp reads row cl of slab 2 p + (kp >> 1), bytes
   // 32 (kp & 1) + [0, 16) and + [16, 32).
   const long wchunk = MODE == 2 ? 16L * a.Cout * 64 : 4L * a.Cout * 64;     // bytes from chunk c to chunk c + 1
@@ -142,71 +179,89 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mb][j] = 0.f;
 
-  // issue state: the tap being streamed, the chunk inside it, the running pointers
-  int tcur = tfirst, ccur = 0;
+  // tap t of this wave -> (ty, tx) of the kernel window
+  auto tap_of = [&](int t, int& ty, int& tx) {
+    const int q = t >> a.lgntx, rem = t & (a.ntx - 1);
+    if (MODE == 1) { ty = a.t0y + q; tx = a.t0x + rem; }
+    else { ty = h == 1 ? (g >> 1) : q; tx = w == 1 ? (g & 1) : rem; }
+  };
+  // ---- weight stream: its own (tap, pair) state ----
+  int wt = tfirst, wc = 0;
   const char* wp;
-  const bf16_t* xp[NB];
-  int xs[NB];
   long ws;
-  auto open_tap = [&]() {
-    const bool live = tcur < ntaps;
-    const int q = tcur >> a.lgntx, rem = tcur & (a.ntx - 1);
+  auto open_w = [&]() {
     int ty, tx;
+    tap_of(wt, ty, tx);
     wp = reinterpret_cast<const char*>(g_small_zero);
     ws = 0;
-    if (MODE == 1) {
-      ty = a.t0y + q; tx = a.t0x + rem;
-      const int rs = (ty & 1) * 2 + (tx & 1), ab = (ty >> 1) * 2 + (tx >> 1);
-      if (live) { wp = wbase + ((long)rs * a.nchunk * 4 + ab) * a.Cout * 64; ws = wstep; }
-    } else {
-      ty = h == 1 ? (g >> 1) : q;
-      tx = w == 1 ? (g & 1) : rem;
-      if (live) { wp = wbase + ((long)(ty * 2 + tx) * 4 + g) * a.Cout * 64; ws = wstep; }
+    if (wt < ntaps) {
+      if (MODE == 1) wp = wbase + ((long)((ty & 1) * 2 + (tx & 1)) * a.nchunk * 4 + (ty >> 1) * 2 + (tx >> 1)) * a.Cout * 64;
+      else wp = wbase + ((long)(ty * 2 + tx) * 4 + g) * a.Cout * 64;
+      ws = wstep;
     }
+  };
+  // ---- pixel stream: global pointers, or byte offsets into the staged LDS image ----
+  int xt = tfirst, xc = 0;
+  const bf16_t* xp[NB];
+  int xs[NB], xo[NB];
+  auto open_x = [&]() {
+    int ty, tx;
+    tap_of(xt, ty, tx);
+    const bool live = xt < ntaps;
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
-      xp[mb] = reinterpret_cast<const bf16_t*>(g_small_zero);
-      xs[mb] = 0;
-      if (MODE == 1) {
-        const int iy = 2 * ry[mb] + ty - 1, ix = 2 * rx[mb] + tx - 1;
-        if (live && rok[mb] && (unsigned)iy < (unsigned)(2 * h) && (unsigned)ix < (unsigned)(2 * w)) {
-          xp[mb] = xlane + ((long)(rn[mb] * 2 * h + iy) * (2 * w) + ix) * a.ldx;
-          xs[mb] = 64;
-        }
+      int iy, ix;
+      if (MODE == 1) { iy = 2 * ry[mb] + ty - 1; ix = 2 * rx[mb] + tx - 1; }
+      else { iy = ry[mb] + ty - (g >> 1); ix = rx[mb] + tx - (g & 1); }
+      const bool ok = live && rok[mb] && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+      if (LDSX) {
+        const int rho = MODE == 1 ? rsl[mb] * a.SP + ((iy & 1) * 2 + (ix & 1)) * (Pin >> 2) + (iy >> 1) * (Win >> 1) + (ix >> 1)
+                                  : rsl[mb] * a.SP + iy * Win + ix;
+        xo[mb] = (ok ? rho : zrow) * pitch + kp * 32;
       } else {
-        const int yy = ry[mb] + ty - (g >> 1), xx = rx[mb] + tx - (g & 1);
-        if (live && rok[mb] && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
-          xp[mb] = xlane + ((long)(rn[mb] * h + yy) * w + xx) * a.ldx;
-          xs[mb] = 64;
-        }
+        xp[mb] = reinterpret_cast<const bf16_t*>(g_small_zero);
+        xs[mb] = 0;
+        if (ok) { xp[mb] = xlane + ((long)(rn[mb] * Hin + iy) * Win + ix) * a.ldx; xs[mb] = 64; }
       }
     }
   };
-  open_tap();
+  open_w();
+  open_x();
 
   bf16x8 Wf[D][2], Xf[D][NB][2];
-  auto issue = [&](auto slotc) {
+  auto issue_w = [&](auto slotc) {
     constexpr int slot = decltype(slotc)::value;
     Wf[slot][0] = *reinterpret_cast<const bf16x8*>(wp);
     Wf[slot][1] = *reinterpret_cast<const bf16x8*>(wp + 16);
     wp += ws;
+    if (++wc == npair) { wc = 0; wt += tstep; open_w(); }          // (wave-uniform) next tap of this wave
+  };
+  auto issue_x = [&](auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
-      Xf[slot][mb][0] = *reinterpret_cast<const bf16x8*>(xp[mb]);
-      Xf[slot][mb][1] = *reinterpret_cast<const bf16x8*>(xp[mb] + 8);
-      xp[mb] += xs[mb];
+      if (LDSX) {
+        const char* q = smem + xo[mb] + xc * 128;
+        Xf[slot][mb][0] = *reinterpret_cast<const bf16x8*>(q);
+        Xf[slot][mb][1] = *reinterpret_cast<const bf16x8*>(q + 16);
+      } else {
+        Xf[slot][mb][0] = *reinterpret_cast<const bf16x8*>(xp[mb]);
+        Xf[slot][mb][1] = *reinterpret_cast<const bf16x8*>(xp[mb] + 8);
+        xp[mb] += xs[mb];
+      }
     }
-    if (++ccur == npair) {                                       // (wave-uniform) next tap of this wave
-      ccur = 0;
-      tcur += tstep;
-      open_tap();
-    }
+    if (++xc == npair) { xc = 0; xt += tstep; open_x(); }
   };
 
   int mytaps = 0;
   for (int t = tfirst; t < ntaps; t += tstep) ++mytaps;
   const int nsteps = mytaps * npair;
-  sfor<D>([&](auto d) { issue(d); });
+  sfor<D>([&](auto d) { issue_w(d); });                 // the weight ring fills while the input image lands
+  if (LDSX) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  sfor<D>([&](auto d) { issue_x(d); });
   for (int base = 0; base < nsteps; base += D) {
     sfor<D>([&](auto d) {
       constexpr int slot = decltype(d)::value;
@@ -215,9 +270,11 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot][0], Xf[slot][mb][0], acc[mb], 0, 0, 0);
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[slot][1], Xf[slot][mb][1], acc[mb], 0, 0, 0);
       }
-      issue(d);
+      issue_w(d);
+      issue_x(d);
     });
   }
+  if (LDSX) __syncthreads();                            // every wave is done with the staged image: the epilogue re-uses it
 
   // ---- the partial tiles meet in LDS: [wave][block][pixel][channel] ----
 #pragma unroll
@@ -384,30 +441,59 @@ __global__ __launch_bounds__(512, 2) void convsm_kernel(SmallArgs a) {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// tile plan of a launch: rows per sample inside one accumulator group, samples per workgroup, pixel blocks
-struct SmallPlan { int P, SG, NB; };
+// tile plan of a launch: rows per sample inside one accumulator group, samples per workgroup, pixel blocks, and whether
+// the samples' input is staged in LDS (whole pixel rows of a multiple of 1 KiB, image <= 144 KiB) with its sample pitch
+struct SmallPlan { int P, SG, NB, ldsx, SP, lds_bytes; };
+inline int small_epi_bytes(int mode, int NB) { const int NQ = (mode == 2 ? 4 : 1) * NB; return (8 * NB + 2 * NQ) * 1024 + 2048; }
 inline bool small_plan(int mode, int B, int h, int w, int Cin, int Cout, SmallPlan* pl) {
   if (mode != 1 && mode != 2) return false;
   if (B <= 0 || !pow2(h) || !pow2(w) || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 16)) return false;
   const int P = h * w;
   if (mode == 1) { if (P > 64) return false; }
-  else if (P > 16) return false;                 // MODE 2: one 16-row block per phase (4 P output pixels <= 64 per sample)
+  else if (P > 16) return false;                 // MODE 2: 4 P output pixels <= 64 per sample
+  const int Pin = mode == 1 ? 4 * P : P;
+  // staged form first: SG samples whose input fits LDS
+  if ((Cin * 2) % 1024 == 0) {
+    int SG, NB;
+    if (P >= 16) { SG = B >= 2 ? 2 : 1; NB = SG * P / 16; }
+    else { SG = 16 / P; NB = 1; }
+    const int SP = (mode == 1 && P < 16) ? Pin + P : Pin;        // (mode 2: a block's samples are P rows apart already)
+    const long xbytes = ((long)SG * SP + 1) * (Cin * 2 + 16);
+    if (NB <= 2 && xbytes <= 144 * 1024) {
+      const int epi = small_epi_bytes(mode, NB);
+      pl->P = P; pl->SG = SG; pl->NB = NB; pl->ldsx = 1; pl->SP = SP;
+      pl->lds_bytes = (int)(xbytes > epi ? xbytes : epi);
+      return true;
+    }
+  }
+  if (mode == 2 && P > 16) return false;
   int SG, NB;
   if (P >= 16) { NB = P / 16; SG = 1; if (mode == 1 && P == 16 && B >= 2) { NB = 2; SG = 2; } }
   else { NB = 1; SG = 16 / P; }
-  if (mode == 1 && NB == 3) return false;
-  pl->P = P; pl->SG = SG; pl->NB = NB;
+  if (NB == 3 || (mode == 2 && NB != 1)) return false;
+  pl->P = P; pl->SG = SG; pl->NB = NB; pl->ldsx = 0; pl->SP = 0; pl->lds_bytes = small_epi_bytes(mode, NB);
   return true;
+}
+
+template <int MODE, int NB, bool LDSX>
+int launch_small(SmallArgs& a, int lds, hipStream_t s) {
+  auto kern = convsm_kernel<MODE, NB, LDSX>;
+  static unsigned long long attr_devs = 0;   // hipFuncSetAttribute is per device
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, &attr_devs)) return rc;
+  hipLaunchKernelGGL(kern, dim3(a.nx * a.ny), dim3(512), lds, s, a);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
 }
 
 }  // namespace
 
 // 1 when (mode, shape) is one of the sample-complete launches below: h x w a power-of-two map (mode 1: the OUTPUT map of
 // the stride-2 convolution, at most 64 pixels; mode 2: the INPUT map of the transposed form, at most 16 pixels),
-// Cin % 64 == 0, Cout % 16 == 0, bf16.
+// Cin % 64 == 0, Cout % 16 == 0, bf16.  Returns 0 (not taken), 1 (taken, pixels streamed from L2) or 2 (taken, input staged in LDS).
 extern "C" int s2s_convsm_ok(int dtype, int mode, int B, int h, int w, int Cin, int Cout) {
   SmallPlan pl;
-  return dtype == S2S_BF16 && small_plan(mode, B, h, w, Cin, Cout, &pl) ? 1 : 0;
+  if (dtype != S2S_BF16 || !small_plan(mode, B, h, w, Cin, Cout, &pl)) return 0;
+  return pl.ldsx ? 2 : 1;        // 2: the samples' input is staged in LDS (the fast form: Cin a multiple of 512, <= 144 KiB)
 }
 
 // epi 0: y = act ? lrelu(conv + bias, slope) : conv + bias, y2 (optional) = relu(y)
@@ -460,12 +546,19 @@ extern "C" int s2s_convsm_nhwc(int dtype, int mode, const void* x, int ldx, int 
   a.stats = stats; a.stats_in = stats_in; a.z = (const bf16_t*)z; a.ldz = ldz; a.g2 = (const bf16_t*)g2; a.ldg2 = ldg2;
   a.bwd_c0 = bwd_c0;
   a.nx = cdiv(B, pl.SG); a.ny = Cout / 16;
-  const dim3 grid(a.nx * a.ny);
+  a.SP = pl.SP;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 2) hipLaunchKernelGGL((convsm_kernel<2, 1>), grid, dim3(512), 0, s, a);
-  else if (pl.NB == 1) hipLaunchKernelGGL((convsm_kernel<1, 1>), grid, dim3(512), 0, s, a);
-  else if (pl.NB == 2) hipLaunchKernelGGL((convsm_kernel<1, 2>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((convsm_kernel<1, 4>), grid, dim3(512), 0, s, a);
-  S2S_LAUNCH_CHECK();
+  const int key = mode * 100 + pl.NB * 10 + pl.ldsx;
+  switch (key) {
+    case 111: return launch_small<1, 1, true>(a, pl.lds_bytes, s);
+    case 121: return launch_small<1, 2, true>(a, pl.lds_bytes, s);
+    case 110: return launch_small<1, 1, false>(a, pl.lds_bytes, s);
+    case 120: return launch_small<1, 2, false>(a, pl.lds_bytes, s);
+    case 140: return launch_small<1, 4, false>(a, pl.lds_bytes, s);
+    case 211: return launch_small<2, 1, true>(a, pl.lds_bytes, s);
+    case 221: return launch_small<2, 2, true>(a, pl.lds_bytes, s);
+    case 210: return launch_small<2, 1, false>(a, pl.lds_bytes, s);
+    default: return S2S_ERR_SHAPE;
+  }
   return S2S_OK;
 }

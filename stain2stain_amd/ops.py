@@ -1498,10 +1498,15 @@ def convsm_bwd(mode: int, g: torch.Tensor, w_packed: torch.Tensor, cout: int, *,
 
 def convsm_wins(dtype: torch.dtype, mode: int, B: int, h: int, w: int, cin: int, cout: int) -> bool:
     """Launch policy of the inner levels: where the sample-complete launch measured faster than split-K convolution +
-    single-launch InstanceNorm at batch 16 (scripts/p2p_small_bench.py, rocprofv3 kernel times).  The launch streams the
-    im2col'd pixels from L2 per workgroup, so it wins on the maps of at most 4x4 (mode 1 with <= 512 output channels) /
-    2x2 (mode 1 with more, mode 2) and loses above."""
-    if not convsm_ok(dtype, mode, B, h, w, cin, cout):
+    single-launch InstanceNorm at batch 16 (scripts/p2p_small_bench.py, rocprofv3 kernel times).  With the samples' input
+    staged in LDS (s2s_convsm_ok() == 2) it takes every layer it fits; the form that streams the im2col'd pixels from L2
+    only wins on the smallest maps."""
+    if dtype != torch.bfloat16:
+        return False
+    how = int(_L().s2s_convsm_ok(BF16, int(mode), int(B), int(h), int(w), int(cin), int(cout)))
+    if how == 2:
+        return True
+    if how == 0:
         return False
     if mode == 1:
         return h * w <= 4 or (h * w <= 16 and cout <= 512)
