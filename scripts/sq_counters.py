@@ -16,8 +16,14 @@ from collections import defaultdict
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
 GROUPS = {"cfm": {"conv3x3 fwd + dgrad (conv3x3_dma16_kernel + conv3x3_pers16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel"),
+                  # per instantiation: the 128-wide tile of the wide layers, the 64-wide one-tile and
+                  # persistent forms of the 64- / 128-channel layers at 256^2 / 128^2
+                  "conv3x3_dma16_kernel<8, 32, 128, 2, 2, 4> (wide layers)": ("conv3x3_dma16_kernel<8, 32, 128, 2, 2, 4>",),
+                  "conv3x3_dma16_kernel<8, 32, 64, 4, 1, 4>": ("conv3x3_dma16_kernel<8, 32, 64, 4, 1, 4>",),
+                  "conv3x3_pers16_kernel (64-wide tiles, persistent walk)": ("conv3x3_pers16_kernel",),
                   "conv3x3_wgrad_dma_kernel": ("conv3x3_wgrad_dma_kernel",)},
           "p2p": {"convkxk_dma16_kernel (4x4 forward / data gradient / transposed)": ("convkxk_dma16_kernel",),
+                  "convsm_kernel (inner levels: conv + norm / data gradient + norm backward in one launch)": ("convsm_kernel",),
                   "convflat_dma16_kernel (inner levels)": ("convflat_dma16_kernel",),
                   "conv2x2_wgrad_dma_kernel": ("conv2x2_wgrad_dma_kernel",)}}
 
@@ -78,6 +84,13 @@ for which, dirs in (("cfm", ["pmc_sq1", "pmc_sq2"]), ("p2p", ["p2p_pmc_sq1"])):
                 e["clock_ghz_from_grbm"] = round(cyc / dur, 3)
                 e["mfma_tflops_from_counters"] = round(tot.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512 / dur / 1e3, 1)
                 e["mfma_frac_of_2.5PF"] = round(e["mfma_tflops_from_counters"] / 2500.0, 4)
+        if wc and tot.get("SQ_WAIT_INST_LDS") is not None and "SQ_WAIT_INST_LDS" in tot:
+            # second pass (pmc_sq2): what the issue stalls are made of, as fractions of the FIRST pass's wave cycles
+            e["wait_inst_lds_frac_of_wave_cycles"] = round(tot["SQ_WAIT_INST_LDS"] / wc, 3)
+        if tot.get("SQ_INSTS_MFMA"):
+            for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS"):
+                if tot.get(c):
+                    e[c.lower() + "_per_mfma"] = round(tot[c] / tot["SQ_INSTS_MFMA"], 2)
         if tot.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"], 4)
         out[label] = e

@@ -73,6 +73,8 @@ if os.path.exists(f"{src}/p2p_pmc_fetch/f_counter_collection.csv"):
     write = per_kernel(f"{src}/p2p_pmc_write/w_counter_collection.csv", "WRITE_SIZE")
     stats = list(csv.DictReader(open(f"{src}/p2p_stats/k_kernel_stats.csv")))
     groups = {"convkxk (4x4 forward / data gradient / transposed)": "convkxk_dma16_kernel",
+              "convsm (inner levels: conv + norm in one launch)": "convsm_kernel",
+              "conv2x2_wgrad_small (inner levels, no slabs)": "conv2x2_wgrad_small_kernel",
               "conv2x2_wgrad (4x4 stride-2 weight gradient)": "conv2x2_wgrad_dma_kernel",
               "convkxk_wgrad_rows (4x4 stride-1 weight gradient)": "convkxk_wgrad_rows_kernel",
               "wgrad_fold4x4": "wgrad_fold4x4_kernel", "instnorm reduce": "in_reduce_kernel",
