@@ -1475,6 +1475,307 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
   return S2S_OK;
 }
 
+// =========================================================================================================
+// WEIGHT-STATIONARY persistent kernel for the 64-input-channel layers (round 4): 64 -> 64 at 256^2 forward and data
+// gradient, the 64 -> 192 data gradient, 64 -> 128 at 128^2.  With K = 9 x 64 the whole packed filter of a 64-channel
+// output tile is 18 slabs x 4 KB = 72 KB: it is loaded into LDS ONCE per workgroup and stays there for the whole tile walk,
+// so that the only operand that still streams is the input halo.  conv3x3_pers16_kernel re-fetches those 72 KB for every
+// 256-pixel tile (118 KB of L2 -> CU traffic per 19 MFLOP, ~60 GB/s per CU at its speed -- the per-CU L2 rate measured in
+// conv_small.hip is ~70 GB/s) and synchronises the workgroup on every tap for the slab ring; here a 512-pixel tile takes
+// 83 KB of halo per 38 MFLOP and TWO barriers:
+//   * one workgroup of 8 waves per CU, tile = 16 x 32 pixels x 64 output channels, wave = 2 tile rows (64 x 64: the same
+//     4 + 4 fragment reads per 16 MFMAs as the 4 x 1 tiles of the kernels above);
+//   * LDS: halo buffer 0 (chunk 0) | halo buffer 1 (chunk 1) | 18 weight slabs = 2 x 41 KB + 72 KB = 154 KB;
+//   * barrier A (chunk-0 halo landed, buffer 1 free) -> DMA this tile's chunk-1 halo -> nine taps on buffer 0 ->
+//     barrier B (chunk-1 halo landed, buffer 0 free) -> DMA the NEXT tile's chunk-0 halo -> nine taps on buffer 1 ->
+//     register epilogue (conv_epilogue16_direct) -> A.  Every halo has one chunk (~2 us) to land; the epilogue's stores
+//     are younger than the halo barrier A waits for and are counted into its vmcnt.
+//   * jobs = (pixel tile, channel tile), channel tile SLOWEST inside an XCD's block of pixel tiles: a workgroup's job list
+//     changes its channel tile at most GY - 1 times, and reloads the filter then.
+// STATS: 0 none, 2 carried over the workgroup's tiles (one row per (workgroup, wave row); GY = 1 only).
+// =========================================================================================================
+template <int STATS, int WM, bool DEFER_EP>
+__global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a, int njobs, int GX, int GY) {
+  using T = bf16_t;
+  constexpr int TH = 16, TW = 32, BN = 64, WN = 1;
+  constexpr int HP = TW + 4, ROWS = (TH + 2) * HP;
+  constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + WM - 1) / WM;
+  constexpr int A_BYTES = NGA * 1024;
+  constexpr int B_BYTES = BN * 64, NSLAB = 18, WG_ = NSLAB * 4 / WM;   // 16-row weight groups per wave
+  constexpr int WTM = TH * TW / WM, MI = WTM / 16, NI = BN / 16, RB = TW / 16;
+  constexpr int NST = MI * (NI / 2);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;
+  char* const ldsB = smem + 2 * A_BYTES;
+  const T* __restrict__ x0 = static_cast<const T*>(a.x0);
+  const T* __restrict__ x1 = static_cast<const T*>(a.x1);
+  const char* __restrict__ wp = static_cast<const char*>(a.w);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave;
+  const int cl = lane & 15, kp = lane >> 4;
+  const int drow = lane >> 2, dslot = lane & 3;
+
+  // halo row / column / piece of this lane's DMA row j (as in conv3x3_pers16_kernel; group = wave + 4 j, groups past the
+  // halo are not issued)
+  int ageo[HG];
+#pragma unroll
+  for (int j = 0; j < HG; ++j) {
+    const int row = (wave + WM * j) * 16 + drow;
+    const int hy = row / HP, hx = row - hy * HP;
+    ageo[j] = (((row < ROWS && hx < TW + 2) ? hy : 0x4000) << 16) | (hx << 8) | ((dslot ^ (((hx >> 2) & 1) << 1)) * 8);
+  }
+  int aofs[RB][3];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int px = rb * 16 + cl + kw;
+      aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ (((px >> 2) & 1) << 1)) << 4);
+    }
+  const int bofs = cl * 64 + ((kp ^ ((-(cl >> 2)) & 3)) << 4);
+
+  struct Tile { int img, y0, x0p, n0; };
+  auto locate = [&](int L) {
+    int bt, by;
+    if (a.xsp) {                                       // XCD x = L & 7 owns pixel tiles [x P, (x + 1) P), all channel tiles
+      const unsigned xcd = (unsigned)L & 7u, k = (unsigned)L >> 3, P = (unsigned)GX >> 3;
+      by = (int)(k / P); bt = (int)(xcd * P + (k - (unsigned)by * P));
+    } else {
+      by = L / GX; bt = L - by * GX;
+    }
+    Tile t;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    t.img = bt / a.tilesY;
+    t.y0 = ty * TH; t.x0p = tx * TW; t.n0 = by * BN;
+    return t;
+  };
+  // the whole filter of channel tile n0: slab it = chunk * 9 + tap at ldsB + it * 4 KB, rows swizzled as the kernels above
+  auto dma_weights = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < WG_; ++j) {
+      const int g = wave + WM * j, it = g >> 2, n = (g & 3) * 16 + drow;
+      const char* src = wp + ((long)it * a.Cout + n0 + n) * 64 + ((dslot ^ ((-(n >> 2)) & 3)) << 4);
+      dma16(n0 + n < a.Cout ? static_cast<const void*>(src) : static_cast<const void*>(g_zero_page), ldsB + g * 1024);
+    }
+  };
+  auto halo_pix = [&](const Tile& t, int (&apix)[HG]) {
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      const int gy = t.y0 - 1 + (ageo[j] >> 16), gx = t.x0p - 1 + ((ageo[j] >> 8) & 0xff);
+      apix[j] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (t.img * a.H + gy) * a.W + gx : -1;
+    }
+  };
+  auto dma_halo = [&](const int (&apix)[HG], int c, int buf) {
+    char* dst = ldsA + buf * A_BYTES + wave * 1024;
+    const bool second = c * 32 >= a.c0;
+    const char* const base = reinterpret_cast<const char*>(second ? x1 : x0);
+    const int ld = second ? a.ld1 : a.ld0, ch0 = c * 32 - (second ? a.c0 : 0);
+#pragma unroll
+    for (int j = 0; j < HG; ++j) {
+      if (wave + WM * j >= NGA || S2S_ABL(a.dbg & 4)) continue;   // (wave-uniform)
+      const unsigned off = ((unsigned)apix[j] * (unsigned)ld + (unsigned)(ch0 + (ageo[j] & 0xff))) * 2u;
+      const void* g = apix[j] >= 0 ? static_cast<const void*>(base + off) : static_cast<const void*>(g_zero_page);
+      dma16(g, dst + j * (WM * 1024));
+    }
+  };
+
+  f32x4 acc[MI][NI];
+  // One chunk = nine taps, no barrier inside.  The fragments are double-buffered by tap parity: the eight ds_read_b128 of
+  // tap t + 1 are issued one per MFMA behind the first eight MFMAs of tap t, the last eight MFMAs cover their latency
+  // (left to the compiler the loop waited `lgkmcnt(0)` right behind freshly issued reads several times per tap).
+  auto frags = [&](auto tapc, const char* Ab, const char* Bb, bf16x8 (&af)[MI], bf16x8 (&bfr)[NI]) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + tap * B_BYTES + bofs + ni * 1024);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+  };
+  // ---- deferred epilogue ----
+  // A tile's accumulators are rounded to bf16 and exchanged (v_permlane16_swap, as conv_epilogue16_direct) right after its
+  // last tap: 32 registers `outv`, eight 16-byte stores per lane.  The stores -- and the statistics taken of the same
+  // bf16 values -- are then issued one unit per tap BEHIND THE MFMAs OF THE NEXT TILE'S FIRST CHUNK: all eight waves pass
+  // barriers A and B together, so an epilogue in place leaves the matrix pipe idle on every SIMD at the same time (22 of
+  // 84 us on 64 -> 64 at 256^2, measured with the epilogue removed).
+  T* __restrict__ yout = static_cast<T*>(a.y);
+  uint4 outv[MI][NI / 2];
+  float cs1[STATS == 2 ? NI / 2 : 1][8], cs2[STATS == 2 ? NI / 2 : 1][8];
+  if constexpr (STATS == 2) {
+#pragma unroll
+    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cs1[pr][k] = 0.f; cs2[pr][k] = 0.f; }
+  }
+  auto pack = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int pr = 0; pr < NI / 2; ++pr) {
+        unsigned w[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          bf16x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)acc[mi][2 * pr + b][j];
+          const uint2 u = __builtin_bit_cast(uint2, pk);
+          w[b][0] = u.x; w[b][1] = u.y;
+        }
+        const auto r0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+        outv[mi][pr] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+  };
+  // unit u = (mi, pr): this lane's pixel of 16-pixel block mi, channels [nl, nl + 8) of channel pair pr
+  auto store_unit = [&](auto uc, const Tile& t) {
+    constexpr int u = decltype(uc)::value, mi = u / (NI / 2), pr = u % (NI / 2);
+    const int m = wm * WTM + mi * 16 + cl;
+    const int gy = t.y0 + m / TW, gx = t.x0p + m % TW;
+    const int n = t.n0 + (kp & 1) * 16 + (kp >> 1) * 8 + pr * 32;
+    if (gy < a.H && gx < a.W && n < a.Cout) {
+      if constexpr (STATS == 2) {
+        const bf16x8 val = __builtin_bit_cast(bf16x8, outv[mi][pr]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = (float)val[k];
+          cs1[pr][k] += v;
+          cs2[pr][k] = fmaf(v, v, cs2[pr][k]);
+        }
+      }
+      if (!S2S_ABL(a.dbg & 8))
+        *reinterpret_cast<uint4*>(yout + ((long)(t.img * a.H + gy) * a.W + gx) * a.ldy + n) = outv[mi][pr];
+    }
+  };
+
+  // DEFER: the previous tile's store units ride, two per tap, behind taps 0 .. NST / 2 - 1
+  auto chunk = [&](auto deferc, const char* Ab, const char* Bb, const Tile& prv) {
+    constexpr bool DEFER = decltype(deferc)::value;
+    bf16x8 af[2][MI], bfr[2][NI];
+    frags(std::integral_constant<int, 0>{}, Ab, Bb, af[0], bfr[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // (these reads, not the next tap's, fill the first group)
+    static_for<9>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value, cb = tap & 1;
+      if constexpr (tap < 8) frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, Ab, Bb, af[cb ^ 1], bfr[cb ^ 1]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cb][ni], af[cb][mi], acc[mi][ni], 0, 0, 0);
+      if constexpr (DEFER && tap < 8) {
+        constexpr int UPT = NST / 8;
+        static_for<UPT>([&](auto k) { store_unit(std::integral_constant<int, (tap < 8 ? tap : 0) * UPT + decltype(k)::value>{}, prv); });
+      }
+      if constexpr (tap < 8) {
+#pragma unroll
+        for (int k = 0; k < MI + NI; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
+      }
+    });
+  };
+
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  Tile cur = locate(L);
+  bool has_next = L + G < njobs;
+  Tile nxt = cur, prv = cur;
+  if (has_next) nxt = locate(L + G);
+  int apix[HG];                                        // halo pixels of the tile whose DMAs are issued next
+  halo_pix(cur, apix);
+  dma_weights(cur.n0);
+  dma_halo(apix, 0, 0);
+  bool pend = false, pend_full = false;                // a packed tile waits in outv / it was a full tile (NST stores)
+
+  for (;;) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<0>();                                      // A: this tile's chunk-0 halo (and the filter) landed; buffer 1 is free
+    __builtin_amdgcn_s_barrier();
+    dma_halo(apix, 1, 1);
+    if (S2S_ABL(a.dbg & 2)) {
+    } else if (pend) chunk(std::true_type{}, ldsA, ldsB, prv);
+    else chunk(std::false_type{}, ldsA, ldsB, prv);
+    __builtin_amdgcn_sched_barrier(0);
+    // B: the chunk-1 halo landed -- younger than it are only the deferred stores of a full previous tile (a partial tile
+    // may have skipped some: drain)
+    if (pend && pend_full) wait_vm<NST>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (has_next) {
+      halo_pix(nxt, apix);
+      dma_halo(apix, 0, 0);
+    }
+    if (!S2S_ABL(a.dbg & 2)) chunk(std::false_type{}, ldsA + A_BYTES, ldsB + 9 * B_BYTES, prv);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!S2S_ABL(a.dbg & 16)) {
+      pack();
+      prv = cur;
+      if constexpr (DEFER_EP) {
+        pend = true;
+        pend_full = cur.y0 + TH <= a.H && cur.x0p + TW <= a.W && cur.n0 + BN <= a.Cout;
+      } else {
+        static_for<NST>([&](auto uc) { store_unit(uc, prv); });
+      }
+    }
+    if (!has_next) break;
+    if (nxt.n0 != cur.n0) {                            // next channel tile: everyone is done with the filter, load the next
+      __builtin_amdgcn_s_barrier();
+      dma_weights(nxt.n0);
+    }
+    L += G;
+    cur = nxt;
+    has_next = L + G < njobs;
+    if (has_next) nxt = locate(L + G);
+  }
+  if (pend) static_for<NST>([&](auto uc) { store_unit(uc, prv); });
+  if constexpr (STATS == 2) conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
+}
+
+// Does this bf16 launch run on the weight-stationary kernel, and on how many workgroups?  (dispatch() and
+// s2s_conv3x3_stat_rows() share the decision: a statistics launch writes grid x 8 rows.)  0 = no.
+inline int wres_grid(const Conv3x3Args& a) {
+  static const int on = [] { const char* e = getenv("S2S_CONV_WRES"); return e ? atoi(e) : 1; }();
+  if (!on || a.c0 + a.c1 != 64 || a.c0 % 32 || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
+  if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9) return 0;
+  const long GX = (long)a.B * cdiv(a.H, 16) * cdiv(a.W, 32), GY = cdiv(a.Cout, 64);
+  const long njobs = GX * GY;
+  constexpr int slots = 256;                           // one workgroup per CU (154 KB of LDS)
+  if (njobs < 3 * slots || njobs > 0x7fffffffL) return 0;   // the 72 KB filter load wants a few tiles to pay for it
+  return slots;
+}
+
+inline int launch_wres(Conv3x3Args& a, int grid, hipStream_t s) {
+  constexpr int lds = 2 * 41 * 1024 + 18 * 4096;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  a.tilesY = cdiv(a.H, 16);
+  a.tilesX = cdiv(a.W, 32);
+  constexpr int WM = 8;
+  auto kern_c = conv3x3_wres_kernel<2, WM, false>;
+  auto kern_d = conv3x3_wres_kernel<0, WM, true>;
+  static unsigned long long attr_c = 0, attr_d = 0;
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_c), lds, &attr_c)) return rc;
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_d), lds, &attr_d)) return rc;
+  const int GX = a.B * a.tilesY * a.tilesX, GY = cdiv(a.Cout, 64);
+  a.xsp = GX % 8 == 0 ? 8 : 0; a.xsn = 1;
+  a.stat_carry = a.stat_part != nullptr;
+  a.stat_rows = (long)grid * WM;
+  if (a.stat_part) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(WM * 64), lds, s, a, GX * GY, GX, GY);
+  else hipLaunchKernelGGL(kern_d, dim3(grid), dim3(WM * 64), lds, s, a, GX * GY, GX, GY);
+  S2S_LAUNCH_CHECK();
+  return S2S_OK;
+}
+
 template <int TH, int TW, int BN, int WM, int WN, int NS>
 int launch_dma16(Conv3x3Args& a, hipStream_t s) {
   constexpr int ROWS = (TH + 2) * (TW + 4);
@@ -2245,6 +2546,11 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
 #endif
   // the training step's launches (forward with BatchNorm statistics, data gradients: no bias, no folded affine, no
   // split-K) run on the persistent kernel; S2S_CONV_PERS=0: one tile per workgroup as before
+  // 64 input channels: the filter stays in LDS (statistics launches only when the caller sized stat_part for it)
+  if (const int wg = wres_grid(a)) {
+    const bool one = a.Cout <= 64;
+    if (!a.stat_part || (one && a.stat_rows_req == (long)wg * 8)) return launch_wres(a, wg, s);
+  }
   if (pers_eligible(a, id)) {
     switch (id) {      // (the 256-pixel x 128-channel tiles, ids 0 and 4, need 128 accumulator + 48 fragment registers: with the
                        //  tile loop's state they spill, so they stay on the one-tile-per-workgroup kernel)
@@ -2378,6 +2684,7 @@ extern "C" int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, i
   Conv3x3Args a{};
   static const float one = 1.f;
   conv3x3_fill_args(a, ld0, c0, ld1, c1, has_bias ? &one : nullptr, B, H, W, Cout);
+  if (const int wg = wres_grid(a)) { if (Cout <= 64) return wg * 8; }
   const int id = select_cfg(dtype, B, H, W, Cout);
   if (!pers_eligible(a, id)) return legacy;
   const TileCfg& tc = kBf16Cfg[id];

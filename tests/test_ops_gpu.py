@@ -6,6 +6,8 @@ Tolerances (max-norm relative, stated per test):
   * bf16 mode vs the oracle evaluated on bf16-rounded operands: 4e-3 for bf16-stored outputs (one bf16
     rounding of the result is 2^-9 = 2e-3), 1e-4 for fp32 outputs (statistics, weight gradients).
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -106,6 +108,41 @@ def test_conv3x3_split_k_small_batch(case):
     assert relerr(nchw(y), (conv * sc[None, :, None, None] + sh[None, :, None, None]).clamp_min(0)) < tol_act(dtype)
     _, st = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, want_stats=True)            # statistics: never split
     assert st is not None and relerr(st[0].sum(1).cpu(), rnd(conv, dtype).sum((0, 2, 3))) < 1e-3
+
+
+WRES_CASES = [
+    # B, H, W, c0, c1, cout, stats   (>= 768 jobs of 16 x 32 pixels x 64 channels: the weight-stationary kernel)
+    (6, 250, 270, 64, 0, 64, True),     # ragged bottom / right tiles, XCD-cut order, carried statistics
+    (6, 240, 270, 32, 32, 64, True),    # two sources; 810 pixel tiles (not a multiple of 8): plain order
+    (2, 250, 270, 64, 0, 192, False),   # three channel tiles: the filter is reloaded twice per workgroup
+    (3, 250, 270, 64, 0, 72, False),    # last channel tile holds 8 channels
+]
+
+
+@pytest.mark.parametrize("case", WRES_CASES)
+def test_conv3x3_weight_stationary_64_channels(case):
+    """64 input channels with many tiles (the 256^2 level of the production step): conv3x3_wres_kernel keeps the whole
+    filter in LDS.  Against torch on bf16-rounded operands, same tolerances as the other bf16 launches."""
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout, stats = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, c0 + c1, H, W, generator=g) * 2 - 1
+    w = (torch.rand(cout, c0 + c1, 3, 3, generator=g) * 2 - 1) * 0.1
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, padding=1)
+    xs = nhwc(x, dtype)
+    x0, x1 = xs[..., :c0], (xs[..., c0:] if c1 else None)
+    wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
+    if stats and os.environ.get("S2S_CONV_WRES", "1") != "0":    # one row per (workgroup, wave row): 256 workgroups x 8
+        assert ops._L().s2s_conv3x3_stat_rows(0, B, H, W, cout, c0, c1, xs.shape[3], xs.shape[3], 0) == 256 * 8
+    y, stat = ops.conv3x3(x0, x1, wf, None, cout, want_stats=stats)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), ref) < tol_act(dtype)
+    if stats:
+        yb = nchw(y)                                   # statistics are taken of the values as stored
+        s = stat.sum(-1).cpu()
+        assert relerr(s[0], yb.sum((0, 2, 3))) < 2e-4
+        assert relerr(s[1], (yb * yb).sum((0, 2, 3))) < 2e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
