@@ -62,10 +62,14 @@ int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x
                        const float* ep_scale, const float* ep_shift, int relu, float* kwork, int B, int H, int W,
                        int Cout, void* stream);
 /* Rows of BatchNorm partial sums a training-step launch of these operands writes (>= 1): s2s_conv3x3_stat_blocks() of
- * them, or one per (workgroup, wave row) when the launch runs on the persistent kernel with a single channel tile (the
- * 64- and 128-channel layers at 256^2 / 128^2: the sums are carried over a workgroup's tiles in registers).  Size
+ * them, or one per (workgroup, wave row) when the launch runs on a persistent kernel that carries the sums over a
+ * workgroup's tiles in registers (the staged kernel; the per-tap persistent kernel with a single channel tile).  Size
  * stat_part as float[2][Cout][rows] and hand `rows` to s2s_conv3x3_nhwc_s (stat_rows = 0: the per-tile count). */
 int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int has_bias);
+/* Which kernel family a bias-free training-step launch of these operands runs on: 0 = the per-tap kernels (one barrier
+ * per filter tap), 1 = conv3x3_stage_kernel streaming its weights per 32-channel chunk, 2 = the same with the filter
+ * resident in LDS (64 input channels).  Diagnostic: tests and scripts assert the path they mean to measure. */
+int s2s_conv3x3_staged(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int ldy, int stats);
 int s2s_conv3x3_nhwc_s(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1, const void* w_packed,
                        const float* bias, void* y, int ldy, float* stat_part, int stat_rows, const float* ep_scale,
                        const float* ep_shift, int relu, float* kwork, int B, int H, int W, int Cout, void* stream);

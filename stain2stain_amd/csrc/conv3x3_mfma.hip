@@ -1476,38 +1476,43 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
 }
 
 // =========================================================================================================
-// WEIGHT-STATIONARY persistent kernel for the 64-input-channel layers (round 4): 64 -> 64 at 256^2 forward and data
-// gradient, the 64 -> 192 data gradient, 64 -> 128 at 128^2.  With K = 9 x 64 the whole packed filter of a 64-channel
-// output tile is 18 slabs x 4 KB = 72 KB: it is loaded into LDS ONCE per workgroup and stays there for the whole tile walk,
-// so that the only operand that still streams is the input halo.  conv3x3_pers16_kernel re-fetches those 72 KB for every
-// 256-pixel tile (118 KB of L2 -> CU traffic per 19 MFLOP, ~60 GB/s per CU at its speed -- the per-CU L2 rate measured in
-// conv_small.hip is ~70 GB/s) and synchronises the workgroup on every tap for the slab ring; here a 512-pixel tile takes
-// 83 KB of halo per 38 MFLOP and TWO barriers:
-//   * one workgroup of 8 waves per CU, tile = 16 x 32 pixels x 64 output channels, wave = 2 tile rows (64 x 64: the same
-//     4 + 4 fragment reads per 16 MFMAs as the 4 x 1 tiles of the kernels above);
-//   * LDS: halo buffer 0 (chunk 0) | halo buffer 1 (chunk 1) | 18 weight slabs = 2 x 41 KB + 72 KB = 154 KB;
-//   * barrier A (chunk-0 halo landed, buffer 1 free) -> DMA this tile's chunk-1 halo -> nine taps on buffer 0 ->
-//     barrier B (chunk-1 halo landed, buffer 0 free) -> DMA the NEXT tile's chunk-0 halo -> nine taps on buffer 1 ->
-//     register epilogue (conv_epilogue16_direct) -> A.  Every halo has one chunk (~2 us) to land; the epilogue's stores
-//     are younger than the halo barrier A waits for and are counted into its vmcnt.
-//   * jobs = (pixel tile, channel tile), channel tile SLOWEST inside an XCD's block of pixel tiles: a workgroup's job list
-//     changes its channel tile at most GY - 1 times, and reloads the filter then.
-// STATS: 0 none, 2 carried over the workgroup's tiles (one row per (workgroup, wave row); GY = 1 only).
+// STAGED persistent kernel (round 4): one workgroup of 8 waves per CU walks 16 x 32-pixel x 64-channel tiles with ONE
+// barrier per 32-channel chunk (nine taps) instead of one per tap.
+//   * LDS = two stages of { halo of one chunk (18 x 36 rows x 64 B = 41 KB) | the chunk's nine weight slabs (36 KB) } =
+//     154 KB.  At the top of a step the workgroup waits for the stage's DMAs (issued one step earlier: a whole chunk,
+//     ~2 us, to land), passes the barrier, issues the NEXT step's DMAs into the other stage -- this tile's next chunk, or
+//     the next tile's first -- and runs nine taps without further synchronisation.
+//   * inside a chunk the fragments are double-buffered by tap parity: the ds_read_b128 of tap t + 1 are issued one per
+//     MFMA behind the first MFMAs of tap t (left to the compiler the loop waited `lgkmcnt(0)` right behind freshly issued
+//     reads several times per tap).  With operands in LDS this loop runs at ~90 % of the MFMA rate the clock allows
+//     (64 -> 64 at 256^2 without DMAs and epilogue: 41 us for 77 GFLOP, profiles/r04_wres_ablation.txt).
+//   * RESIDENT (64 input channels: 64 -> 64 at 256^2 forward and data gradient, the 64 -> 192 data gradient): the two
+//     chunks' slabs ARE the whole filter of a channel tile (72 KB): they are loaded once and stay; only halos stream, and
+//     jobs are ordered channel tile slowest so that a workgroup reloads the filter at most GY - 1 times.  The per-tap
+//     kernels above re-fetch those 72 KB for every 256-pixel tile.
+//   * streaming (any other channel count): jobs are ordered channel tile fastest inside an XCD's block of pixel tiles, so
+//     the GY workgroups that share a pixel tile run at the same time and its halo comes from the XCD's L2.
+//   * DEFER_EP (launches without statistics): a tile's accumulators are rounded and exchanged right after its last tap
+//     (32 registers), and the 16-byte stores are issued one per tap behind the MFMAs of the next tile's first chunk: all
+//     waves pass the barriers together, so an epilogue in place leaves the matrix pipe idle on every SIMD at once.
+//   * STATS = 2: BatchNorm partial sums carried in registers over the workgroup's tiles of one channel tile, written as row
+//     (workgroup, wave row) when the channel tile changes and at the end; channel tiles a workgroup never visited get
+//     zero rows.  stat_part is [2][Cout][workgroups x 8].
 // =========================================================================================================
-template <int STATS, int WM, bool DEFER_EP>
-__global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a, int njobs, int GX, int GY) {
+template <int STATS, bool DEFER_EP, bool RESIDENT>
+__global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, int njobs, int GX, int GY) {
   using T = bf16_t;
-  constexpr int TH = 16, TW = 32, BN = 64, WN = 1;
+  constexpr int TH = 16, TW = 32, BN = 64, WM = 8, WN = 1;
   constexpr int HP = TW + 4, ROWS = (TH + 2) * HP;
   constexpr int NGA = (ROWS + 15) / 16, HG = (NGA + WM - 1) / WM;
   constexpr int A_BYTES = NGA * 1024;
-  constexpr int B_BYTES = BN * 64, NSLAB = 18, WG_ = NSLAB * 4 / WM;   // 16-row weight groups per wave
+  constexpr int B_BYTES = BN * 64, NGB = 9 * 4, BGW = (NGB + WM - 1) / WM;   // 16-row weight groups of a chunk / per wave
+  constexpr int STAGE = A_BYTES + 9 * B_BYTES;
   constexpr int WTM = TH * TW / WM, MI = WTM / 16, NI = BN / 16, RB = TW / 16;
   constexpr int NST = MI * (NI / 2);
+  static_assert(NST <= 8, "one deferred store unit per tap");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const ldsA = smem;
-  char* const ldsB = smem + 2 * A_BYTES;
   const T* __restrict__ x0 = static_cast<const T*>(a.x0);
   const T* __restrict__ x1 = static_cast<const T*>(a.x1);
   const char* __restrict__ wp = static_cast<const char*>(a.w);
@@ -1517,8 +1522,9 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
   const int wm = wave;
   const int cl = lane & 15, kp = lane >> 4;
   const int drow = lane >> 2, dslot = lane & 3;
+  const int ctot = a.c0 + a.c1;
 
-  // halo row / column / piece of this lane's DMA row j (as in conv3x3_pers16_kernel; group = wave + 4 j, groups past the
+  // halo row / column / piece of this lane's DMA row j (as in conv3x3_pers16_kernel; group = wave + 8 j, groups past the
   // halo are not issued)
   int ageo[HG];
 #pragma unroll
@@ -1535,16 +1541,19 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
       const int px = rb * 16 + cl + kw;
       aofs[rb][kw] = ((wm * (WTM / TW)) * HP + px) * 64 + ((kp ^ (((px >> 2) & 1) << 1)) << 4);
     }
-  const int bofs = cl * 64 + ((kp ^ ((-(cl >> 2)) & 3)) << 4);
+  int bofs = cl * 64 + ((kp ^ ((-(cl >> 2)) & 3)) << 4);
 
   struct Tile { int img, y0, x0p, n0; };
   auto locate = [&](int L) {
     int bt, by;
     if (a.xsp) {                                       // XCD x = L & 7 owns pixel tiles [x P, (x + 1) P), all channel tiles
       const unsigned xcd = (unsigned)L & 7u, k = (unsigned)L >> 3, P = (unsigned)GX >> 3;
-      by = (int)(k / P); bt = (int)(xcd * P + (k - (unsigned)by * P));
-    } else {
+      if constexpr (RESIDENT) { by = (int)(k / P); bt = (int)(xcd * P + (k - (unsigned)by * P)); }
+      else { const unsigned kq = k / (unsigned)GY; by = (int)(k - kq * (unsigned)GY); bt = (int)(xcd * P + kq); }
+    } else if constexpr (RESIDENT) {
       by = L / GX; bt = L - by * GX;
+    } else {
+      bt = L / GY; by = L - bt * GY;
     }
     Tile t;
     const int tx = bt % a.tilesX; bt /= a.tilesX;
@@ -1553,13 +1562,27 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
     t.y0 = ty * TH; t.x0p = tx * TW; t.n0 = by * BN;
     return t;
   };
-  // the whole filter of channel tile n0: slab it = chunk * 9 + tap at ldsB + it * 4 KB, rows swizzled as the kernels above
-  auto dma_weights = [&](int n0) {
+  // Operand DMAs: buffer_load_dwordx4 ... lds through raw buffer resources -- a scalar base, a 32-bit byte offset per
+  // lane, and ZERO FILL for offsets past num_records: padding pixels, rows past Cout and channel pieces past the input
+  // take the offset OOB, so there is no zero page, no 64-bit address per lane and no pointer select (scripts/probe/
+  // buffer_lds_probe.hip checks the destination layout and the zero fill on the device).
+  constexpr unsigned OOB = 0xffffff00u;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, (int)((long)a.nchunk * 9 * a.Cout * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x0), 0, (int)(((long)a.B * a.H * a.W - 1) * a.ld0 + a.c0) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.c1 ? x1 : x0), 0, a.c1 ? (int)(((long)a.B * a.H * a.W - 1) * a.ld1 + a.c1) * 2 : 0, 0x00020000);
+  // the nine slabs of chunk c, channel tile n0, into stage `st` (rows swizzled as the kernels above).  Group g = wave + 8 j
+  // is rows (g & 3) * 16 + drow of slab g >> 2: the row is the same for every j, only the slab (a scalar) moves
+  const int wrow = (wave & 3) * 16 + drow;
+  const unsigned wsw = (unsigned)wrow * 64u + (unsigned)((dslot ^ ((-(wrow >> 2)) & 3)) << 4);
+  auto dma_weights = [&](int n0, int c, int st) {
+    char* dst = smem + st * STAGE + A_BYTES + wave * 1024;
+    const unsigned voff = n0 + wrow < a.Cout ? wsw : OOB;
 #pragma unroll
-    for (int j = 0; j < WG_; ++j) {
-      const int g = wave + WM * j, it = g >> 2, n = (g & 3) * 16 + drow;
-      const char* src = wp + ((long)it * a.Cout + n0 + n) * 64 + ((dslot ^ ((-(n >> 2)) & 3)) << 4);
-      dma16(n0 + n < a.Cout ? static_cast<const void*>(src) : static_cast<const void*>(g_zero_page), ldsB + g * 1024);
+    for (int j = 0; j < BGW; ++j) {
+      if (wave + WM * j >= NGB || S2S_ABL(a.dbg & 1)) continue;   // (wave-uniform)
+      const int tap = (wave >> 2) + (WM / 4) * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(dst + j * (WM * 1024)), 16, voff,
+                                               ((c * 9 + tap) * a.Cout + n0) * 64, 0, 0);
     }
   };
   auto halo_pix = [&](const Tile& t, int (&apix)[HG]) {
@@ -1569,48 +1592,48 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
       apix[j] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (t.img * a.H + gy) * a.W + gx : -1;
     }
   };
-  auto dma_halo = [&](const int (&apix)[HG], int c, int buf) {
-    char* dst = ldsA + buf * A_BYTES + wave * 1024;
+  auto dma_halo = [&](const int (&apix)[HG], int c, int st) {
+    char* dst = smem + st * STAGE + wave * 1024;
     const bool second = c * 32 >= a.c0;
-    const char* const base = reinterpret_cast<const char*>(second ? x1 : x0);
-    const int ld = second ? a.ld1 : a.ld0, ch0 = c * 32 - (second ? a.c0 : 0);
+    const int ld2 = (second ? a.ld1 : a.ld0) * 2, ch0 = c * 32 - (second ? a.c0 : 0);
+    const int left = ctot - c * 32;                    // channels of this chunk that exist (< 32 only when ctot % 32 != 0)
 #pragma unroll
     for (int j = 0; j < HG; ++j) {
       if (wave + WM * j >= NGA || S2S_ABL(a.dbg & 4)) continue;   // (wave-uniform)
-      const unsigned off = ((unsigned)apix[j] * (unsigned)ld + (unsigned)(ch0 + (ageo[j] & 0xff))) * 2u;
-      const void* g = apix[j] >= 0 ? static_cast<const void*>(base + off) : static_cast<const void*>(g_zero_page);
-      dma16(g, dst + j * (WM * 1024));
+      const int pc = ageo[j] & 0xff;
+      const unsigned voff = (apix[j] >= 0 && pc < left) ? (unsigned)apix[j] * (unsigned)ld2 + (unsigned)(pc * 2) : OOB;
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void_t*)(dst + j * (WM * 1024)), 16, voff, ch0 * 2, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_void_t*)(dst + j * (WM * 1024)), 16, voff, ch0 * 2, 0, 0);
     }
   };
 
   f32x4 acc[MI][NI];
-  // One chunk = nine taps, no barrier inside.  The fragments are double-buffered by tap parity: the eight ds_read_b128 of
-  // tap t + 1 are issued one per MFMA behind the first eight MFMAs of tap t, the last eight MFMAs cover their latency
-  // (left to the compiler the loop waited `lgkmcnt(0)` right behind freshly issued reads several times per tap).
-  auto frags = [&](auto tapc, const char* Ab, const char* Bb, bf16x8 (&af)[MI], bf16x8 (&bfr)[NI]) {
+  // (aofs / bofs are the CURRENT stage's byte offsets into smem: step() moves them by +-STAGE, everything else in a
+  //  fragment address is an instruction immediate)
+  auto frags = [&](auto tapc, bf16x8 (&af)[MI], bf16x8 (&bfr)[NI]) {
     constexpr int tap = decltype(tapc)::value;
     constexpr int kh = tap / 3, kw = tap % 3;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(Bb + tap * B_BYTES + bofs + ni * 1024);
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(smem + bofs + (A_BYTES + tap * B_BYTES + ni * 1024));
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
-      af[mi] = *reinterpret_cast<const bf16x8*>(Ab + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+      af[mi] = *reinterpret_cast<const bf16x8*>(smem + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
   };
-  // ---- deferred epilogue ----
-  // A tile's accumulators are rounded to bf16 and exchanged (v_permlane16_swap, as conv_epilogue16_direct) right after its
-  // last tap: 32 registers `outv`, eight 16-byte stores per lane.  The stores -- and the statistics taken of the same
-  // bf16 values -- are then issued one unit per tap BEHIND THE MFMAs OF THE NEXT TILE'S FIRST CHUNK: all eight waves pass
-  // barriers A and B together, so an epilogue in place leaves the matrix pipe idle on every SIMD at the same time (22 of
-  // 84 us on 64 -> 64 at 256^2, measured with the epilogue removed).
+
+  // ---- epilogue: rounded + exchanged values (v_permlane16_swap, as conv_epilogue16_direct), then one 16-byte store per
+  // unit u = (mi, pr): this lane's pixel of 16-pixel block mi, eight channels of channel pair pr ----
   T* __restrict__ yout = static_cast<T*>(a.y);
   uint4 outv[MI][NI / 2];
   float cs1[STATS == 2 ? NI / 2 : 1][8], cs2[STATS == 2 ? NI / 2 : 1][8];
-  if constexpr (STATS == 2) {
+  auto stats_zero = [&]() {
+    if constexpr (STATS == 2) {
 #pragma unroll
-    for (int pr = 0; pr < NI / 2; ++pr)
+      for (int pr = 0; pr < NI / 2; ++pr)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { cs1[pr][k] = 0.f; cs2[pr][k] = 0.f; }
-  }
+        for (int k = 0; k < 8; ++k) { cs1[pr][k] = 0.f; cs2[pr][k] = 0.f; }
+    }
+  };
+  stats_zero();
   auto pack = [&]() {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1630,45 +1653,47 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
         outv[mi][pr] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
       }
   };
-  // unit u = (mi, pr): this lane's pixel of 16-pixel block mi, channels [nl, nl + 8) of channel pair pr
+  // Stores go through a raw buffer resource as well: the tile / unit part of the address is a scalar offset, the lane's
+  // part (pixel column cl, its eight channels) ONE tile-invariant register, and lanes outside the image or past Cout take
+  // the offset out of range -- the hardware drops them (scripts/probe/buffer_store_probe.hip), so a store unit has no
+  // branch and the chunk stays one scheduling region.
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yout, 0, (int)(((long)a.B * a.H * a.W - 1) * a.ldy + a.Cout) * 2, 0x00020000);
+  const int nl = (kp & 1) * 16 + (kp >> 1) * 8;
+  const unsigned vst = (unsigned)(cl * a.ldy + nl) * 2u;
   auto store_unit = [&](auto uc, const Tile& t) {
     constexpr int u = decltype(uc)::value, mi = u / (NI / 2), pr = u % (NI / 2);
-    const int m = wm * WTM + mi * 16 + cl;
-    const int gy = t.y0 + m / TW, gx = t.x0p + m % TW;
-    const int n = t.n0 + (kp & 1) * 16 + (kp >> 1) * 8 + pr * 32;
-    if (gy < a.H && gx < a.W && n < a.Cout) {
-      if constexpr (STATS == 2) {
-        const bf16x8 val = __builtin_bit_cast(bf16x8, outv[mi][pr]);
+    const int gy = t.y0 + wm * (WTM / TW) + mi / RB, gx0 = t.x0p + (mi % RB) * 16, nb = t.n0 + pr * 32;   // (scalars)
+    const bool ok = gy < a.H && gx0 + cl < a.W && nb + nl < a.Cout;
+    if constexpr (STATS == 2) {
+      const bf16x8 val = __builtin_bit_cast(bf16x8, outv[mi][pr]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float v = (float)val[k];
-          cs1[pr][k] += v;
-          cs2[pr][k] = fmaf(v, v, cs2[pr][k]);
-        }
+      for (int k = 0; k < 8; ++k) {
+        const float v = ok ? (float)val[k] : 0.f;
+        cs1[pr][k] += v;
+        cs2[pr][k] = fmaf(v, v, cs2[pr][k]);
       }
-      if (!S2S_ABL(a.dbg & 8))
-        *reinterpret_cast<uint4*>(yout + ((long)(t.img * a.H + gy) * a.W + gx) * a.ldy + n) = outv[mi][pr];
     }
+    if (!S2S_ABL(a.dbg & 8))
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, outv[mi][pr]), rs_y, ok ? vst : OOB,
+                                             (((t.img * a.H + gy) * a.W + gx0) * a.ldy + nb) * 2, 0);
   };
 
-  // DEFER: the previous tile's store units ride, two per tap, behind taps 0 .. NST / 2 - 1
-  auto chunk = [&](auto deferc, const char* Ab, const char* Bb, const Tile& prv) {
+  // One chunk = nine taps on stage `st`.  DEFER: the previous tile's store units ride behind taps 0 .. NST - 1.
+  auto chunk = [&](auto deferc, const Tile& prv) {
     constexpr bool DEFER = decltype(deferc)::value;
     bf16x8 af[2][MI], bfr[2][NI];
-    frags(std::integral_constant<int, 0>{}, Ab, Bb, af[0], bfr[0]);
+    frags(std::integral_constant<int, 0>{}, af[0], bfr[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // (these reads, not the next tap's, fill the first group)
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value, cb = tap & 1;
-      if constexpr (tap < 8) frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, Ab, Bb, af[cb ^ 1], bfr[cb ^ 1]);
+      if constexpr (tap < 8) frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, af[cb ^ 1], bfr[cb ^ 1]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cb][ni], af[cb][mi], acc[mi][ni], 0, 0, 0);
-      if constexpr (DEFER && tap < 8) {
-        constexpr int UPT = NST / 8;
-        static_for<UPT>([&](auto k) { store_unit(std::integral_constant<int, (tap < 8 ? tap : 0) * UPT + decltype(k)::value>{}, prv); });
-      }
+      if constexpr (DEFER && tap < NST) store_unit(std::integral_constant<int, (tap < NST ? tap : 0)>{}, prv);
       if constexpr (tap < 8) {
 #pragma unroll
         for (int k = 0; k < MI + NI; ++k) {
@@ -1688,10 +1713,47 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
   if (has_next) nxt = locate(L + G);
   int apix[HG];                                        // halo pixels of the tile whose DMAs are issued next
   halo_pix(cur, apix);
-  dma_weights(cur.n0);
   dma_halo(apix, 0, 0);
+  dma_weights(cur.n0, 0, 0);
+  if constexpr (RESIDENT) dma_weights(cur.n0, 1, 1);
   bool pend = false, pend_full = false;                // a packed tile waits in outv / it was a full tile (NST stores)
+  bool ynst = false;                                   // exactly NST stores are younger than the newest DMA
+  int st = 0;
+  const int by_first = cur.n0 / BN;
 
+  auto step = [&](int c, auto mayc) {
+    constexpr bool MAY_DEFER = decltype(mayc)::value;
+    // this step's operands were issued one step ago; younger than them are at most the NST stores of a full tile
+    if (ynst) wait_vm<NST>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                      // ... landed for every wave, and everyone is past the previous step
+    ynst = false;
+    if (c + 1 < a.nchunk) {
+      dma_halo(apix, c + 1, st ^ 1);
+      if constexpr (!RESIDENT) dma_weights(cur.n0, c + 1, st ^ 1);
+    } else if (has_next) {                             // (this tile's halos are all issued: apix moves on to the next tile)
+      halo_pix(nxt, apix);
+      dma_halo(apix, 0, st ^ 1);
+      if constexpr (!RESIDENT) dma_weights(nxt.n0, 0, st ^ 1);
+    }
+    if (S2S_ABL(a.dbg & 2)) {
+    } else if (MAY_DEFER && pend) {
+      chunk(std::true_type{}, prv);
+      ynst = pend_full;
+      pend = false;
+    } else {
+      chunk(std::false_type{}, prv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int d = st ? -STAGE : STAGE;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) aofs[rb][kw] += d;
+      bofs += d;
+    }
+    st ^= 1;
+  };
   for (;;) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1701,37 +1763,34 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[mi][ni][j] = 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    wait_vm<0>();                                      // A: this tile's chunk-0 halo (and the filter) landed; buffer 1 is free
-    __builtin_amdgcn_s_barrier();
-    dma_halo(apix, 1, 1);
-    if (S2S_ABL(a.dbg & 2)) {
-    } else if (pend) chunk(std::true_type{}, ldsA, ldsB, prv);
-    else chunk(std::false_type{}, ldsA, ldsB, prv);
-    __builtin_amdgcn_sched_barrier(0);
-    // B: the chunk-1 halo landed -- younger than it are only the deferred stores of a full previous tile (a partial tile
-    // may have skipped some: drain)
-    if (pend && pend_full) wait_vm<NST>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (has_next) {
-      halo_pix(nxt, apix);
-      dma_halo(apix, 0, 0);
-    }
-    if (!S2S_ABL(a.dbg & 2)) chunk(std::false_type{}, ldsA + A_BYTES, ldsB + 9 * B_BYTES, prv);
-    __builtin_amdgcn_sched_barrier(0);
+    // (the first chunk apart: the deferred stores ride only there, so `outv` is dead in the loop over the others)
+    step(0, std::integral_constant<bool, DEFER_EP>{});
+    for (int c = 1; c < a.nchunk; ++c) step(c, std::false_type{});
     if (!S2S_ABL(a.dbg & 16)) {
       pack();
       prv = cur;
+      const bool full = cur.y0 + TH <= a.H && cur.x0p + TW <= a.W && cur.n0 + BN <= a.Cout;
       if constexpr (DEFER_EP) {
         pend = true;
-        pend_full = cur.y0 + TH <= a.H && cur.x0p + TW <= a.W && cur.n0 + BN <= a.Cout;
+        pend_full = full;
       } else {
         static_for<NST>([&](auto uc) { store_unit(uc, prv); });
+        ynst = full;
       }
     }
     if (!has_next) break;
-    if (nxt.n0 != cur.n0) {                            // next channel tile: everyone is done with the filter, load the next
-      __builtin_amdgcn_s_barrier();
-      dma_weights(nxt.n0);
+    if (nxt.n0 != cur.n0) {
+      if constexpr (STATS == 2) {                      // (a wave row's sums of this channel tile: written once)
+        conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
+        stats_zero();
+        ynst = false;
+      }
+      if constexpr (RESIDENT) {                        // everyone is done with the filter: load the next channel tile's
+        __builtin_amdgcn_s_barrier();
+        dma_weights(nxt.n0, 0, 0);
+        dma_weights(nxt.n0, 1, 1);
+        ynst = false;
+      }
     }
     L += G;
     cur = nxt;
@@ -1739,39 +1798,57 @@ __global__ __launch_bounds__(WM * 64, 1) void conv3x3_wres_kernel(Conv3x3Args a,
     if (has_next) nxt = locate(L + G);
   }
   if (pend) static_for<NST>([&](auto uc) { store_unit(uc, prv); });
-  if constexpr (STATS == 2) conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
+  if constexpr (STATS == 2) {
+    conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
+    // zero rows for the channel tiles this workgroup never visited: RESIDENT job lists are monotonic in the channel tile;
+    // streaming ones keep ONE channel tile per workgroup (stage_grid() admits statistics only when GY divides 32)
+    stats_zero();
+    const int by_last = cur.n0 / BN;
+    for (int by = 0; by < GY; ++by) {
+      if (by < by_first || by > by_last) conv_stats_flush<BN, WN>(a, cs1, cs2, by * BN, tid, (long)blockIdx.x * WM + wm);
+    }
+  }
 }
 
-// Does this bf16 launch run on the weight-stationary kernel, and on how many workgroups?  (dispatch() and
-// s2s_conv3x3_stat_rows() share the decision: a statistics launch writes grid x 8 rows.)  0 = no.
-inline int wres_grid(const Conv3x3Args& a) {
-  static const int on = [] { const char* e = getenv("S2S_CONV_WRES"); return e ? atoi(e) : 1; }();
-  if (!on || a.c0 + a.c1 != 64 || a.c0 % 32 || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
-  if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9) return 0;
+// Does this bf16 launch run on the staged kernel, and on how many workgroups?  (dispatch() and s2s_conv3x3_stat_rows()
+// share the decision: a statistics launch writes grid x 8 rows.)  0 = no.
+inline int stage_grid(const Conv3x3Args& a, bool stats) {
+  static const int on = [] { const char* e = getenv("S2S_CONV_STAGE"); return e ? atoi(e) : 1; }();
+  if (!on || a.c0 % 32 || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
+  if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9 ||
+      (double)a.B * a.H * a.W * a.ldy * 2 >= 4.0e9) return 0;          // 32-bit byte offsets into each tensor
   const long GX = (long)a.B * cdiv(a.H, 16) * cdiv(a.W, 32), GY = cdiv(a.Cout, 64);
   const long njobs = GX * GY;
   constexpr int slots = 256;                           // one workgroup per CU (154 KB of LDS)
-  if (njobs < 3 * slots || njobs > 0x7fffffffL) return 0;   // the 72 KB filter load wants a few tiles to pay for it
+  if (njobs < 2L * slots || njobs > 0x7fffffffL) return 0;             // a walk of one tile buys nothing
+  // Measured against the per-tap kernels on the production shapes (batch 16, scripts/conv_bench.py, round 4): the resident
+  // form wins everywhere it applies (64 -> 64 at 256^2: 108 -> 83 us, the 64 -> 192 data gradient 283 -> 215 us); the
+  // streaming form wins with ONE channel tile (192 -> 64 at 256^2: 232 -> 211 us, the 128 -> 64 data gradient 52 -> 50 us)
+  // and ties or loses by up to 15 % with more (128 -> 128 at 128^2: 81 = 81 us, 256 -> 256 at 64^2: 69 -> 78 us) -- those
+  // stay on the per-tap kernels.  S2S_CONV_STAGE=2 admits them too (the parity tests do, to cover the order and the
+  // statistics rows of GY > 1).
+  if (a.c0 + a.c1 != 64 && GY > 1 && on < 2) return 0;
+  // statistics are carried per (workgroup, channel tile): the streaming order keeps one channel tile per workgroup only
+  // when GY divides the 32 workgroups of an XCD
+  if (stats && a.c0 + a.c1 != 64 && (GY > 32 || (32 % GY))) return 0;
   return slots;
 }
 
-inline int launch_wres(Conv3x3Args& a, int grid, hipStream_t s) {
-  constexpr int lds = 2 * 41 * 1024 + 18 * 4096;
+inline int launch_stage(Conv3x3Args& a, int grid, hipStream_t s) {
+  constexpr int lds = 2 * (41 * 1024 + 9 * 4096);
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, 16);
   a.tilesX = cdiv(a.W, 32);
-  constexpr int WM = 8;
-  auto kern_c = conv3x3_wres_kernel<2, WM, false>;
-  auto kern_d = conv3x3_wres_kernel<0, WM, true>;
-  static unsigned long long attr_c = 0, attr_d = 0;
-  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_c), lds, &attr_c)) return rc;
-  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern_d), lds, &attr_d)) return rc;
+  const bool resident = a.c0 + a.c1 == 64;
+  auto kern = a.stat_part ? (resident ? conv3x3_stage_kernel<2, false, true> : conv3x3_stage_kernel<2, false, false>)
+                          : (resident ? conv3x3_stage_kernel<0, true, true> : conv3x3_stage_kernel<0, true, false>);
+  static unsigned long long attr[4] = {0, 0, 0, 0};
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr[(a.stat_part ? 2 : 0) + (resident ? 1 : 0)])) return rc;
   const int GX = a.B * a.tilesY * a.tilesX, GY = cdiv(a.Cout, 64);
   a.xsp = GX % 8 == 0 ? 8 : 0; a.xsn = 1;
   a.stat_carry = a.stat_part != nullptr;
-  a.stat_rows = (long)grid * WM;
-  if (a.stat_part) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(WM * 64), lds, s, a, GX * GY, GX, GY);
-  else hipLaunchKernelGGL(kern_d, dim3(grid), dim3(WM * 64), lds, s, a, GX * GY, GX, GY);
+  a.stat_rows = (long)grid * 8;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, GX * GY, GX, GY);
   S2S_LAUNCH_CHECK();
   return S2S_OK;
 }
@@ -2546,10 +2623,9 @@ int dispatch(int dtype, Conv3x3Args& a, hipStream_t s) {
 #endif
   // the training step's launches (forward with BatchNorm statistics, data gradients: no bias, no folded affine, no
   // split-K) run on the persistent kernel; S2S_CONV_PERS=0: one tile per workgroup as before
-  // 64 input channels: the filter stays in LDS (statistics launches only when the caller sized stat_part for it)
-  if (const int wg = wres_grid(a)) {
-    const bool one = a.Cout <= 64;
-    if (!a.stat_part || (one && a.stat_rows_req == (long)wg * 8)) return launch_wres(a, wg, s);
+  // many tiles: the staged kernel, one barrier per chunk (statistics launches only when the caller sized stat_part for it)
+  if (const int wg = stage_grid(a, a.stat_part != nullptr)) {
+    if (!a.stat_part || a.stat_rows_req == (long)wg * 8) return launch_stage(a, wg, s);
   }
   if (pers_eligible(a, id)) {
     switch (id) {      // (the 256-pixel x 128-channel tiles, ids 0 and 4, need 128 accumulator + 48 fragment registers: with the
@@ -2684,7 +2760,7 @@ extern "C" int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, i
   Conv3x3Args a{};
   static const float one = 1.f;
   conv3x3_fill_args(a, ld0, c0, ld1, c1, has_bias ? &one : nullptr, B, H, W, Cout);
-  if (const int wg = wres_grid(a)) { if (Cout <= 64) return wg * 8; }
+  if (const int wg = stage_grid(a, true)) return wg * 8;
   const int id = select_cfg(dtype, B, H, W, Cout);
   if (!pers_eligible(a, id)) return legacy;
   const TileCfg& tc = kBf16Cfg[id];
@@ -2692,6 +2768,17 @@ extern "C" int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, i
   if (GY != 1) return legacy;
   static const int wm_of[8] = {2, 4, 2, 2, 2, 4, 2, 2};
   return pers_plan(a, GX, GY).grid * wm_of[id];
+}
+
+extern "C" int s2s_conv3x3_staged(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int ldy,
+                                  int stats) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || c0 <= 0 || c1 < 0) return S2S_ERR_SHAPE;
+  if (dtype != S2S_BF16) return 0;
+  Conv3x3Args a{};
+  conv3x3_fill_args(a, ld0, c0, ld1, c1, nullptr, B, H, W, Cout);
+  a.ldy = ldy;
+  if (!stage_grid(a, stats != 0)) return 0;
+  return c0 + c1 == 64 ? 2 : 1;
 }
 
 extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,

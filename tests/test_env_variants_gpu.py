@@ -3,7 +3,8 @@ run the convolution parity tests in child processes, so that a non-default path 
   S2S_CONV_XCD=0, S2S_WGRAD_XCD=0   plain (not XCD-aware) workgroup order
   S2S_WGRAD_BLOCKS=512    two weight-gradient workgroups per CU (default: one), without the fill rule
   S2S_CONV_PERS=0         one tile per workgroup also for the >= 1024-tile launches (default: persistent tile walk)
-  S2S_CONV_WRES=0         64-input-channel launches on the streaming kernels (default: filter resident in LDS)
+  S2S_CONV_STAGE=0 / 2    no launch / every eligible launch on the staged kernel (default 1: filter-resident and
+                          single-channel-tile launches)
 (Round 4 deleted what rounds 2-3 had measured and dropped: S2S_WGRAD_KH, S2S_WGRAD_MFMA, S2S_WGRAD_DMA, S2S_CONV_EPI and
 the tuning knobs whose sweeps ended at their defaults.)"""
 import os
@@ -15,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-VARIANTS = [{"S2S_CONV_XCD": "0", "S2S_WGRAD_XCD": "0"}, {"S2S_WGRAD_BLOCKS": "512"}, {"S2S_CONV_PERS": "0"}, {"S2S_CONV_WRES": "0"}]
+VARIANTS = [{"S2S_CONV_XCD": "0", "S2S_WGRAD_XCD": "0"}, {"S2S_WGRAD_BLOCKS": "512"}, {"S2S_CONV_PERS": "0"}, {"S2S_CONV_STAGE": "0"}, {"S2S_CONV_STAGE": "2"}]
 # (The earlier forms of the forward loop, S2S_CONV_DMA=1/3/0, and the result-changing S2S_CONV_DBG timing bits are NOT in
 #  the product library any more: they are compiled only with -DS2S_ABLATE into libstain2stain_hip_ablate.so, which
 #  scripts/ load; tests/test_native_cpu.py checks that the shipped sources read no such switch outside that guard.)

@@ -135,7 +135,7 @@ def test_product_library_has_no_result_changing_switches():
     assert "S2S_CONV_DMA" not in envs, envs.get("S2S_CONV_DMA")
     # what remains is result-preserving (tile choice, workgroup order, split counts, equivalent kernels): each is either
     # exercised by tests/test_env_variants_gpu.py or changes launch geometry only
-    allowed = {"S2S_CONV_DBG", "S2S_CONV_CFG", "S2S_CONV_PERS", "S2S_CONV_WRES", "S2S_CONV_XCD", "S2S_WGRAD_XCD", "S2S_WGRAD_BLOCKS",
+    allowed = {"S2S_CONV_DBG", "S2S_CONV_CFG", "S2S_CONV_PERS", "S2S_CONV_STAGE", "S2S_CONV_XCD", "S2S_WGRAD_XCD", "S2S_WGRAD_BLOCKS",
                "S2S_P2P_WGRAD_BLOCKS", "S2S_P2P_WGRAD_S1_BLOCKS", "S2S_UP_BAND"}
     assert len(allowed) <= 12          # what was measured and dropped is deleted, not switched off
     assert set(envs) <= allowed, set(envs) - allowed

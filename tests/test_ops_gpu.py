@@ -110,21 +110,33 @@ def test_conv3x3_split_k_small_batch(case):
     assert st is not None and relerr(st[0].sum(1).cpu(), rnd(conv, dtype).sum((0, 2, 3))) < 1e-3
 
 
-WRES_CASES = [
-    # B, H, W, c0, c1, cout, stats   (>= 768 jobs of 16 x 32 pixels x 64 channels: the weight-stationary kernel)
-    (6, 250, 270, 64, 0, 64, True),     # ragged bottom / right tiles, XCD-cut order, carried statistics
-    (6, 240, 270, 32, 32, 64, True),    # two sources; 810 pixel tiles (not a multiple of 8): plain order
-    (2, 250, 270, 64, 0, 192, False),   # three channel tiles: the filter is reloaded twice per workgroup
-    (3, 250, 270, 64, 0, 72, False),    # last channel tile holds 8 channels
+STAGE_CASES = [
+    # B, H, W, c0, c1, cout, stats, level   (>= 512 jobs of 16 x 32 pixels x 64 channels: conv3x3_stage_kernel;
+    #  level = the S2S_CONV_STAGE value from which the launch is staged: 1 = default, 2 = also streaming with several
+    #  channel tiles -- tests/test_env_variants_gpu.py runs this file under 0 and 2 --, 9 = never)
+    (6, 250, 270, 64, 0, 64, True, 1),      # filter resident; ragged bottom / right tiles, XCD-cut order
+    (6, 240, 270, 32, 32, 64, True, 1),     # resident, two sources; 810 pixel tiles (not a multiple of 8): plain order
+    (2, 250, 270, 64, 0, 192, False, 1),    # resident, three channel tiles: the filter is reloaded twice per workgroup
+    (3, 250, 270, 64, 0, 72, False, 1),     # resident, last channel tile holds 8 channels
+    (3, 250, 270, 64, 0, 128, True, 1),     # resident with statistics over two channel tiles (flushed at the change)
+    (16, 100, 130, 64, 128, 64, True, 1),   # streaming, six chunks from two sources (the decoder's concat)
+    (13, 120, 130, 128, 0, 40, False, 1),   # streaming, one partial channel tile (a data gradient's shape)
+    (8, 120, 130, 128, 0, 128, True, 2),    # streaming: one channel tile per workgroup, zero rows for the other
+    (8, 120, 130, 32, 8, 128, False, 2),    # streaming, 40 input channels: the second chunk holds 8
+    (5, 120, 130, 128, 0, 192, False, 2),   # streaming, three channel tiles (a workgroup cycles through them)
+    (5, 120, 130, 128, 0, 192, True, 9),    # ... with statistics: never staged (3 does not divide 32), per-tap kernels
+    (1, 64, 64, 128, 0, 128, True, 9),      # few tiles: per-tap kernels
 ]
 
 
-@pytest.mark.parametrize("case", WRES_CASES)
-def test_conv3x3_weight_stationary_64_channels(case):
-    """64 input channels with many tiles (the 256^2 level of the production step): conv3x3_wres_kernel keeps the whole
-    filter in LDS.  Against torch on bf16-rounded operands, same tolerances as the other bf16 launches."""
+@pytest.mark.parametrize("case", STAGE_CASES)
+def test_conv3x3_staged_kernel(case):
+    """Launches with many tiles (the upper levels of the production step) run on conv3x3_stage_kernel: one barrier per
+    32-channel chunk, operands by buffer loads with zero fill, deferred / carried epilogues.  Against torch on bf16-rounded
+    operands, same tolerances as the other bf16 launches."""
     from stain2stain_amd import ops
-    B, H, W, c0, c1, cout, stats = case
+    B, H, W, c0, c1, cout, stats, level = case
+    mode = int(os.environ.get("S2S_CONV_STAGE", "1"))
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(21)
     x = torch.rand(B, c0 + c1, H, W, generator=g) * 2 - 1
@@ -133,7 +145,9 @@ def test_conv3x3_weight_stationary_64_channels(case):
     xs = nhwc(x, dtype)
     x0, x1 = xs[..., :c0], (xs[..., c0:] if c1 else None)
     wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
-    if stats and os.environ.get("S2S_CONV_WRES", "1") != "0":    # one row per (workgroup, wave row): 256 workgroups x 8
+    path = ops._L().s2s_conv3x3_staged(0, B, H, W, cout, c0, c1, xs.shape[3], xs.shape[3], cout, int(stats))
+    assert path == ((2 if c0 + c1 == 64 else 1) if mode >= level else 0)
+    if stats and path:                                 # staged: one row per (workgroup, wave row), 256 x 8
         assert ops._L().s2s_conv3x3_stat_rows(0, B, H, W, cout, c0, c1, xs.shape[3], xs.shape[3], 0) == 256 * 8
     y, stat = ops.conv3x3(x0, x1, wf, None, cout, want_stats=stats)
     torch.cuda.synchronize()
