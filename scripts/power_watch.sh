@@ -5,9 +5,24 @@ label=$1; shift
 out=$(mktemp)
 ( while true; do rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n' >> "$out"; echo >> "$out"; sleep 0.2; done ) &
 wpid=$!
+e0=$(rocm-smi --showenergycounter --json 2>/dev/null | tr -d '\n')
+t0=$(date +%s.%N)
 "$@"
 rc=$?
+t1=$(date +%s.%N)
+e1=$(rocm-smi --showenergycounter --json 2>/dev/null | tr -d '\n')
 kill $wpid 2>/dev/null
+python3 - "$e0" "$e1" "$t0" "$t1" <<'PY'
+import json, sys
+try:
+    a, b = (json.loads(x)["card0"] for x in sys.argv[1:3])
+    k = [k for k in a if "ccumulated" in k or "nergy" in k]
+    ja = float(a[[x for x in k if "uJ" in x or "Accumulated" in x][0]]); jb = float(b[[x for x in k if "uJ" in x or "Accumulated" in x][0]])
+    dt = float(sys.argv[4]) - float(sys.argv[3])
+    print(f"[power_watch] energy {((jb - ja) / 1e6):.1f} J over {dt:.1f} s wall = {(jb - ja) / 1e6 / dt:.0f} W mean (whole process, incl. start-up); keys {k}")
+except Exception as e:
+    print("[power_watch] no energy counter:", e, sys.argv[1][:200])
+PY
 python3 - "$label" "$out" <<'PY'
 import json, re, sys
 label, path = sys.argv[1], sys.argv[2]

@@ -1610,14 +1610,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   f32x4 acc[MI][NI];
   // (aofs / bofs are the CURRENT stage's byte offsets into smem: step() moves them by +-STAGE, everything else in a
   //  fragment address is an instruction immediate)
-  auto frags = [&](auto tapc, bf16x8 (&af)[MI], bf16x8 (&bfr)[NI]) {
+  auto afrag = [&](auto tapc, int mi) {
     constexpr int tap = decltype(tapc)::value;
     constexpr int kh = tap / 3, kw = tap % 3;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(smem + bofs + (A_BYTES + tap * B_BYTES + ni * 1024));
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      af[mi] = *reinterpret_cast<const bf16x8*>(smem + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+    return *reinterpret_cast<const bf16x8*>(smem + aofs[mi % RB][kw] + (kh + mi / RB) * HP * 64);
+  };
+  auto bfrag = [&](auto tapc, int ni) {
+    constexpr int tap = decltype(tapc)::value;
+    return *reinterpret_cast<const bf16x8*>(smem + bofs + (A_BYTES + tap * B_BYTES + ni * 1024));
   };
 
   // ---- epilogue: rounded + exchanged values (v_permlane16_swap, as conv_epilogue16_direct), then one 16-byte store per
@@ -1682,29 +1682,53 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   // One chunk = nine taps on stage `st`.  DEFER: the previous tile's store units ride behind taps 0 .. NST - 1.
   auto chunk = [&](auto deferc, const Tile& prv) {
     constexpr bool DEFER = decltype(deferc)::value;
-    bf16x8 af[2][MI], bfr[2][NI];
-    frags(std::integral_constant<int, 0>{}, af[0], bfr[0]);
+    // Fragments: the pixel (A) side double-buffered by tap parity, the weight (B) side in ONE set -- the MFMAs run channel
+    // block by channel block, and block ni's fragment of the next tap is read as soon as its four MFMAs are issued (it is
+    // needed twelve MFMAs later).  Per tap: four A reads behind the first four MFMAs, then one B read per channel block.
+    bf16x8 af[2][MI], bfr[NI];
+    using T0 = std::integral_constant<int, 0>;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = bfrag(T0{}, ni);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[0][mi] = afrag(T0{}, mi);
     __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // (these reads, not the next tap's, fill the first group)
     static_for<9>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value, cb = tap & 1;
-      if constexpr (tap < 8) frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, af[cb ^ 1], bfr[cb ^ 1]);
+      using TN = std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cb][ni], af[cb][mi], acc[mi][ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[cb][mi], acc[mi][ni], 0, 0, 0);
+          if (tap < 8 && ni == 0) af[cb ^ 1][mi] = afrag(TN{}, mi);
+        }
+        if (tap < 8) bfr[ni] = bfrag(TN{}, ni);
+      }
       if constexpr (DEFER && tap < NST) store_unit(std::integral_constant<int, (tap < NST ? tap : 0)>{}, prv);
       if constexpr (tap < 8) {
 #pragma unroll
-        for (int k = 0; k < MI + NI; ++k) {
+        for (int k = 0; k < MI; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int k = 1; k < NI; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
     });
   };
 
+  // Phase offset: the 256 workgroups have identical work and start together, so without it the whole chip alternates
+  // between "every CU issues its DMAs" and "every CU runs MFMAs" -- operand traffic and matrix work do not overlap ACROSS
+  // CUs, and the 256^2 layers this kernel serves are the HBM-heaviest of the step.  Workgroup w of an XCD sleeps
+  // (w mod 16) x 0.66 us before its first DMA: 16 phases over ~10 us, about one tile period of 64 -> 64.  Measured on the
+  // sustained CFM step (1000 steps, same box): 7.66 ms without, 7.62 / 7.45 / 7.45 / 7.33 / 7.20 / 7.32 ms with 0.22 /
+  // 0.44 / 0.66 / 0.88 / 1.3 / 1.8 us per phase (per-tap kernels throughout: 7.65 ms) -- the offset costs the last phase's
+  // delay once per launch and returns several times that.
+  for (int i = 0, d = 3 * (int)((blockIdx.x >> 3) & 15); i < d; ++i) __builtin_amdgcn_s_sleep(8);
   const int G = gridDim.x;
   int L = blockIdx.x;
   Tile cur = locate(L);

@@ -244,6 +244,8 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// (Round 4 also tried a start-up phase offset per workgroup, as conv3x3_stage_kernel has: nothing gained here, 7.13 -> 7.16
+// ... 7.24 ms per step for 0.4 ... 1.8 us of offset per phase -- two workgroups per CU already drift apart.)
 // A workgroup accumulates all nine taps (one dY fragment feeds nine MFMAs).  (Rounds 2-3 also built the kernel rows over
 // three workgroups, over the three 4-wave teams of a 12-wave workgroup, a two-team pixel split and a 16x16x32-MFMA form:
 // all parity-green, all 8-18 % slower -- DESIGN.md section 3.2 -- and deleted in round 4.)
