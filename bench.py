@@ -328,7 +328,7 @@ def multitask_bench(args, dev, rank: int, world: int, use_dist: bool, tile: int,
                    "grad_exchange": (tr.fp.bucketer.mode if tr.fp.bucketer.enabled else "none"),
                    "algorithmic_gflop_per_tile": round(fl / 1e9, 1),
                    "step_tflops": round(fl * batch * steps / elapsed / 1e12, 1)},
-        "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
+        "roofline": {"bound": "mfma", "kernel": "conv3x3 fwd + dgrad launches (conv3x3_dma16_kernel; conv3x3_stage_kernel on the 256^2 level)",
                      "achieved": round(f_l / t_l / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(f_l / t_l / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                      "launches_per_step": n_l // max(timed_steps, 1), "launches_timed": n_l,
@@ -788,7 +788,7 @@ def main() -> None:
                        "launch": _launch_note(trainer.graph),
                        ("eager_ms_per_step" if trainer.graph else "graph_ms_per_step"): other_ms,
                        "buckets_mb": [round((hi - lo) * 4 / 2 ** 20, 2) for _, lo, hi in trainer.bucketer.buckets]},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_dma16_kernel (fwd + dgrad launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3 fwd + dgrad launches (conv3x3_dma16_kernel; conv3x3_stage_kernel on the 256^2 level)",
                          "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/hbm_traffic_current.json)",

@@ -15,12 +15,13 @@ from collections import defaultdict
 
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
-GROUPS = {"cfm": {"conv3x3 fwd + dgrad (conv3x3_dma16_kernel + conv3x3_pers16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel"),
+GROUPS = {"cfm": {"conv3x3 fwd + dgrad (conv3x3_dma16_kernel + conv3x3_stage_kernel + conv3x3_pers16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel", "conv3x3_stage_kernel"),
                   # per instantiation: the 128-wide tile of the wide layers, the 64-wide one-tile and
                   # persistent forms of the 64- / 128-channel layers at 256^2 / 128^2
                   "conv3x3_dma16_kernel<8, 32, 128, 2, 2, 4> (wide layers)": ("conv3x3_dma16_kernel<8, 32, 128, 2, 2, 4>",),
                   "conv3x3_dma16_kernel<8, 32, 64, 4, 1, 4>": ("conv3x3_dma16_kernel<8, 32, 64, 4, 1, 4>",),
                   "conv3x3_pers16_kernel (64-wide tiles, persistent walk)": ("conv3x3_pers16_kernel",),
+                  "conv3x3_stage_kernel (256^2 level: filter resident / streaming, one barrier per chunk)": ("conv3x3_stage_kernel",),
                   "conv3x3_wgrad_dma_kernel": ("conv3x3_wgrad_dma_kernel",)},
           "p2p": {"convkxk_dma16_kernel (4x4 forward / data gradient / transposed)": ("convkxk_dma16_kernel",),
                   "convsm_kernel (inner levels: conv + norm / data gradient + norm backward in one launch)": ("convsm_kernel",),

@@ -31,7 +31,7 @@ def _has(needle, name):
     return any(n in name for n in needle) if isinstance(needle, tuple) else needle in name
 
 
-groups = {"conv3x3_mfma (fwd+dgrad: conv3x3_pers16_kernel + conv3x3_dma16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel"),
+groups = {"conv3x3_mfma (fwd+dgrad: conv3x3_dma16_kernel + conv3x3_stage_kernel + conv3x3_pers16_kernel)": ("conv3x3_dma16_kernel", "conv3x3_pers16_kernel", "conv3x3_stage_kernel"),
           "conv3x3_wgrad (conv3x3_wgrad_dma_kernel)": "conv3x3_wgrad_dma_kernel",
           "bn_relu_apply": "bn_relu_apply_kernel", "bn_relu_bwd_reduce_flat": "bn_relu_bwd_reduce_flat_kernel",
           "bn_relu_bwd_apply_flat": "bn_relu_bwd_apply_flat_kernel", "upsample2x_fwd": "upsample2x_fwd_kernel",

@@ -1485,7 +1485,7 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
 //   * inside a chunk the fragments are double-buffered by tap parity: the ds_read_b128 of tap t + 1 are issued one per
 //     MFMA behind the first MFMAs of tap t (left to the compiler the loop waited `lgkmcnt(0)` right behind freshly issued
 //     reads several times per tap).  With operands in LDS this loop runs at ~90 % of the MFMA rate the clock allows
-//     (64 -> 64 at 256^2 without DMAs and epilogue: 41 us for 77 GFLOP, profiles/r04_wres_ablation.txt).
+//     (64 -> 64 at 256^2 without DMAs and epilogue: 41 us for 77 GFLOP, profiles/r04_stage_ablation.txt).
 //   * RESIDENT (64 input channels: 64 -> 64 at 256^2 forward and data gradient, the 64 -> 192 data gradient): the two
 //     chunks' slabs ARE the whole filter of a channel tile (72 KB): they are loaded once and stay; only halos stream, and
 //     jobs are ordered channel tile slowest so that a workgroup reloads the filter at most GY - 1 times.  The per-tap
