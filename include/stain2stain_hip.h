@@ -68,7 +68,7 @@ int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x
 int s2s_conv3x3_stat_rows(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int has_bias);
 /* Which kernel family a bias-free training-step launch of these operands runs on: 0 = the per-tap kernels (one barrier
  * per filter tap), 1 = conv3x3_stage_kernel streaming its weights per 32-channel chunk, 2 = the same with the filter
- * resident in LDS (64 input channels).  Diagnostic: tests and scripts assert the path they mean to measure. */
+ * resident in LDS (<= 64 input channels).  Diagnostic: tests and scripts assert the path they mean to measure. */
 int s2s_conv3x3_staged(int dtype, int B, int H, int W, int Cout, int c0, int c1, int ld0, int ld1, int ldy, int stats);
 int s2s_conv3x3_nhwc_s(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1, const void* w_packed,
                        const float* bias, void* y, int ldy, float* stat_part, int stat_rows, const float* ep_scale,

@@ -1486,8 +1486,8 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
 //     MFMA behind the first MFMAs of tap t (left to the compiler the loop waited `lgkmcnt(0)` right behind freshly issued
 //     reads several times per tap).  With operands in LDS this loop runs at ~90 % of the MFMA rate the clock allows
 //     (64 -> 64 at 256^2 without DMAs and epilogue: 41 us for 77 GFLOP, profiles/r04_stage_ablation.txt).
-//   * RESIDENT (64 input channels: 64 -> 64 at 256^2 forward and data gradient, the 64 -> 192 data gradient): the two
-//     chunks' slabs ARE the whole filter of a channel tile (72 KB): they are loaded once and stay; only halos stream, and
+//   * RESIDENT (<= 64 input channels: 64 -> 64 at 256^2 forward and data gradient, the 64 -> 192 data gradient, the stem
+//     on its 8-channel NHWC image): the two stages' slabs ARE the whole filter of a channel tile (<= 72 KB): they are loaded once and stay; only halos stream, and
 //     jobs are ordered channel tile slowest so that a workgroup reloads the filter at most GY - 1 times.  The per-tap
 //     kernels above re-fetch those 72 KB for every 256-pixel tile.
 //   * streaming (any other channel count): jobs are ordered channel tile fastest inside an XCD's block of pixel tiles, so
@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   halo_pix(cur, apix);
   dma_halo(apix, 0, 0);
   dma_weights(cur.n0, 0, 0);
-  if constexpr (RESIDENT) dma_weights(cur.n0, 1, 1);
+  if constexpr (RESIDENT) dma_weights(cur.n0, a.nchunk > 1 ? 1 : 0, 1);   // (one chunk: both stages hold it)
   bool pend = false, pend_full = false;                // a packed tile waits in outv / it was a full tile (NST stores)
   bool ynst = false;                                   // exactly NST stores are younger than the newest DMA
   int st = 0;
@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
       if constexpr (RESIDENT) {                        // everyone is done with the filter: load the next channel tile's
         __builtin_amdgcn_s_barrier();
         dma_weights(nxt.n0, 0, 0);
-        dma_weights(nxt.n0, 1, 1);
+        dma_weights(nxt.n0, a.nchunk > 1 ? 1 : 0, 1);
         ynst = false;
       }
     }
@@ -1838,7 +1838,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
 // share the decision: a statistics launch writes grid x 8 rows.)  0 = no.
 inline int stage_grid(const Conv3x3Args& a, bool stats) {
   static const int on = [] { const char* e = getenv("S2S_CONV_STAGE"); return e ? atoi(e) : 1; }();
-  if (!on || a.c0 % 32 || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
+  if (!on || (a.c1 && a.c0 % 32) || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
   if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9 ||
       (double)a.B * a.H * a.W * a.ldy * 2 >= 4.0e9) return 0;          // 32-bit byte offsets into each tensor
   const long GX = (long)a.B * cdiv(a.H, 16) * cdiv(a.W, 32), GY = cdiv(a.Cout, 64);
@@ -1851,10 +1851,10 @@ inline int stage_grid(const Conv3x3Args& a, bool stats) {
   // and ties or loses by up to 15 % with more (128 -> 128 at 128^2: 81 = 81 us, 256 -> 256 at 64^2: 69 -> 78 us) -- those
   // stay on the per-tap kernels.  S2S_CONV_STAGE=2 admits them too (the parity tests do, to cover the order and the
   // statistics rows of GY > 1).
-  if (a.c0 + a.c1 != 64 && GY > 1 && on < 2) return 0;
+  if (a.c0 + a.c1 > 64 && GY > 1 && on < 2) return 0;
   // statistics are carried per (workgroup, channel tile): the streaming order keeps one channel tile per workgroup only
   // when GY divides the 32 workgroups of an XCD
-  if (stats && a.c0 + a.c1 != 64 && (GY > 32 || (32 % GY))) return 0;
+  if (stats && a.c0 + a.c1 > 64 && (GY > 32 || (32 % GY))) return 0;
   return slots;
 }
 
@@ -1863,7 +1863,7 @@ inline int launch_stage(Conv3x3Args& a, int grid, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tilesY = cdiv(a.H, 16);
   a.tilesX = cdiv(a.W, 32);
-  const bool resident = a.c0 + a.c1 == 64;
+  const bool resident = a.c0 + a.c1 <= 64;             // one or two chunks: the whole filter fits the two stages
   auto kern = a.stat_part ? (resident ? conv3x3_stage_kernel<2, false, true> : conv3x3_stage_kernel<2, false, false>)
                           : (resident ? conv3x3_stage_kernel<0, true, true> : conv3x3_stage_kernel<0, true, false>);
   static unsigned long long attr[4] = {0, 0, 0, 0};
@@ -2802,7 +2802,7 @@ extern "C" int s2s_conv3x3_staged(int dtype, int B, int H, int W, int Cout, int 
   conv3x3_fill_args(a, ld0, c0, ld1, c1, nullptr, B, H, W, Cout);
   a.ldy = ldy;
   if (!stage_grid(a, stats != 0)) return 0;
-  return c0 + c1 == 64 ? 2 : 1;
+  return c0 + c1 <= 64 ? 2 : 1;
 }
 
 extern "C" int s2s_conv3x3_nhwc_k(int dtype, const void* x0, int ld0, int c0, const void* x1, int ld1, int c1,

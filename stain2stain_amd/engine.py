@@ -237,6 +237,19 @@ class DecCtx:
     v: torch.Tensor = None
 
 
+def _stem_as_conv(x_nchw: torch.Tensor, dtype: torch.dtype) -> bool:
+    """bf16 mode, <= 8 image channels: the stem runs as a generic conv3x3 on an 8-channel NHWC bf16 copy of the image
+    (one 16 MB pack launch), i.e. at 256^2 on conv3x3_stage_kernel with its 3 -> 64 filter resident in LDS.
+    stem_mfma_kernel builds its im2col patch per 16 x 16 tile with ~1850 vector instructions per wave (rocprofv3
+    SQ_INSTS_VALU, profiles/r04_b): 109 us for a layer whose output is 134 MB.  fp32 parity mode keeps that kernel."""
+    return dtype == torch.bfloat16 and x_nchw.shape[1] <= 8
+
+
+def _stem_image(x_nchw: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    B, _, H, W = x_nchw.shape
+    return ops.p2p_pack_input(x_nchw, None, torch.empty((B, H, W, 8), dtype=dtype, device=x_nchw.device))
+
+
 def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = False, stem: bool = False):
     """Returns (LayerCtx or None, act, pooled)."""
     bn = cb.bn
@@ -247,7 +260,10 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         # enters the running mean (ops.bn_finalize, conv_bias).  The saved conv output and the saved mean are both those
         # of the unbiased convolution, so the backward is unchanged.  (fp32 parity mode and the stem add it as before.)
         late_bias = None
-        if stem:
+        if stem and _stem_as_conv(x0, dtype):
+            raw, stat = ops.conv3x3(_stem_image(x0, dtype), None, cb.packed(dtype)[0], None, cb.cout, want_stats=True)
+            late_bias = bias
+        elif stem:
             raw, stat = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=True)
         elif dtype == torch.bfloat16 and bias is not None:
             raw, stat = ops.conv3x3(x0, x1, cb.packed(dtype)[0], None, cb.cout, want_stats=True)
@@ -273,7 +289,10 @@ def _conv_bn_relu(cb: ConvBN, x0, x1, dtype, training: bool, want_pool: bool = F
         act, pooled = ops.bn_relu_apply(raw, st[2], st[3], want_pool=want_pool)
         return LayerCtx(x0, x1, raw, act, st, count if sx is not None else None, sx), act, pooled
     ss = cb.eval_affine()
-    if stem:
+    if stem and _stem_as_conv(x0, dtype):
+        act, _ = ops.conv3x3(_stem_image(x0, dtype), None, cb.packed(dtype)[0], bias, cb.cout, scale=ss[0], shift=ss[1], relu=True)
+        pooled = ops.maxpool2(act) if want_pool else None
+    elif stem:
         raw, _ = ops.stem_fwd(x0, cb.conv.weight.detach(), bias, dtype, want_stats=False)
         act, pooled = ops.bn_relu_apply(raw, ss[0], ss[1], want_pool=want_pool)
     else:
@@ -361,7 +380,8 @@ def encoder_forward(blocks: Sequence[Tuple[ConvBN, ConvBN]], x_nchw: torch.Tenso
     """blocks[l] = (conv1, conv2) of level l (l = 0 is ``inc``).  Keeps every level's activation."""
     ctx = EncCtx(dtype, x_nchw)
     nlev = len(blocks)
-    repack_stale([cb for l, pair in enumerate(blocks) for j, cb in enumerate(pair) if (l, j) != (0, 0)], dtype)   # (the stem reads the fp32 master)
+    repack_stale([cb for l, pair in enumerate(blocks) for j, cb in enumerate(pair)
+                  if (l, j) != (0, 0) or _stem_as_conv(x_nchw, dtype)], dtype)   # (the fp32-mode stem reads the master)
     inp = x_nchw
     for l, (c1, c2) in enumerate(blocks):
         lc1, a1, _ = _conv_bn_relu(c1, inp, None, dtype, training, stem=(l == 0))

@@ -93,9 +93,10 @@ class MultiTaskTrainer:
         self.grads_seg = {k[len("seg_decoder."):]: v for k, v in gr.items() if k.startswith("seg_decoder.")}
         from .ddp import broadcast_from_rank0
         broadcast_from_rank0([b for m in (encoder, flow_decoder, seg_decoder) for b in m.buffers()], process_group)
-        # one launch re-packs every MFMA conv's weights (all but the stem, which reads the fp32 master directly)
+        # one launch re-packs every MFMA conv's weights (in fp32 mode all but the stem, which reads the master directly)
         blocks = list(encoder._blocks) + list(flow_decoder.up_blocks) + list(seg_decoder.up_blocks)
-        self._packed = [cb for pair in blocks for cb in pair if cb is not encoder._blocks[0][0]]
+        self._packed = [cb for pair in blocks for cb in pair if cb is not encoder._blocks[0][0] or
+                        (self._dtype == torch.bfloat16 and cb.cin <= 8)]     # (the bf16 stem runs as a packed conv too)
         rows, start = [], 0
         for cb in self._packed:
             wf, wd = cb.ensure_buffers(self._dtype)

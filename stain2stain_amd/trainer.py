@@ -146,9 +146,10 @@ class CFMTrainer:
         self._sync_bn = engine.SyncBNExchange(process_group) if sync_batchnorm and self.bucketer.enabled else None
         broadcast_from_rank0([self.flat_p] + [b for b in net.buffers()], process_group)
         self._blocks = list(net.encoder._blocks) + list(net.flow_decoder.up_blocks)
-        # one launch re-packs every MFMA conv's weights (all but the stem, which reads the fp32 master directly)
+        # one launch re-packs every MFMA conv's weights (in fp32 mode all but the stem, which reads the master directly)
         self._dtype = net.encoder.compute_dtype
-        self._packed = [cb for pair in self._blocks for cb in pair if cb is not net.encoder._blocks[0][0]]
+        self._packed = [cb for pair in self._blocks for cb in pair if cb is not net.encoder._blocks[0][0] or
+                        (self._dtype == torch.bfloat16 and cb.cin <= 8)]     # (the bf16 stem runs as a packed conv too)
         rows, start = [], 0
         for cb in self._packed:
             wf, wd = cb.ensure_buffers(self._dtype)
