@@ -1499,7 +1499,7 @@ int launch_pers16(Conv3x3Args& a, hipStream_t s) {
 //     (workgroup, wave row) when the channel tile changes and at the end; channel tiles a workgroup never visited get
 //     zero rows.  stat_part is [2][Cout][workgroups x 8].
 // =========================================================================================================
-template <int STATS, bool DEFER_EP, bool RESIDENT>
+template <int STATS, bool DEFER_EP, bool RESIDENT, bool AFFINE = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, int njobs, int GX, int GY) {
   using T = bf16_t;
   constexpr int TH = 16, TW = 32, BN = 64, WM = 8, WN = 1;
@@ -1634,6 +1634,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
     }
   };
   stats_zero();
+  // AFFINE (the eval-mode forward of the sampler: conv bias + folded BatchNorm + ReLU): y = max(acc * esc + esh', 0) with
+  // esh' = bias * esc + esh, this lane's sixteen channels of the current channel tile kept in registers
+  float esc[AFFINE ? NI : 1][4], esh[AFFINE ? NI : 1][4];
+  auto load_affine = [&](int n0) {
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + ni * 16 + 4 * kp;           // (Cout % 8 == 0: four channels are in or out together)
+        const bool ok = n < a.Cout;
+        const f32x4 sc = ok ? *reinterpret_cast<const f32x4*>(a.ep_scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = ok ? *reinterpret_cast<const f32x4*>(a.ep_shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bi = (ok && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { esc[ni][j] = sc[j]; esh[ni][j] = fmaf(bi[j], sc[j], sh[j]); }
+      }
+    }
+  };
   auto pack = [&]() {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1644,7 +1661,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
         for (int b = 0; b < 2; ++b) {
           bf16x4 pk;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pk[j] = (bf16_t)acc[mi][2 * pr + b][j];
+          for (int j = 0; j < 4; ++j) {
+            float t = acc[mi][2 * pr + b][j];
+            if constexpr (AFFINE) {
+              t = fmaf(t, esc[2 * pr + b][j], esh[2 * pr + b][j]);
+              if (a.relu) t = fmaxf(t, 0.f);
+            }
+            pk[j] = (bf16_t)t;
+          }
           const uint2 u = __builtin_bit_cast(uint2, pk);
           w[b][0] = u.x; w[b][1] = u.y;
         }
@@ -1740,6 +1764,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   dma_halo(apix, 0, 0);
   dma_weights(cur.n0, 0, 0);
   if constexpr (RESIDENT) dma_weights(cur.n0, a.nchunk > 1 ? 1 : 0, 1);   // (one chunk: both stages hold it)
+  load_affine(cur.n0);
   bool pend = false, pend_full = false;                // a packed tile waits in outv / it was a full tile (NST stores)
   bool ynst = false;                                   // exactly NST stores are younger than the newest DMA
   int st = 0;
@@ -1804,6 +1829,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
     }
     if (!has_next) break;
     if (nxt.n0 != cur.n0) {
+      load_affine(nxt.n0);                             // (pack() of the current tile is done)
       if constexpr (STATS == 2) {                      // (a wave row's sums of this channel tile: written once)
         conv_stats_flush<BN, WN>(a, cs1, cs2, cur.n0, tid, (long)blockIdx.x * WM + wm);
         stats_zero();
@@ -1838,7 +1864,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
 // share the decision: a statistics launch writes grid x 8 rows.)  0 = no.
 inline int stage_grid(const Conv3x3Args& a, bool stats) {
   static const int on = [] { const char* e = getenv("S2S_CONV_STAGE"); return e ? atoi(e) : 1; }();
-  if (!on || (a.c1 && a.c0 % 32) || a.bias || a.ep_scale || a.kpart || a.act || a.y2 || !a.direct_ep || (a.dbg & 64)) return 0;
+  // (a folded affine -- the eval-mode forward -- has its own instantiation; a bias alone or statistics beside an affine do not)
+  if (!on || (a.c1 && a.c0 % 32) || (a.bias && !a.ep_scale) || (a.ep_scale && stats) || a.kpart || a.act || a.y2 ||
+      !a.direct_ep || (a.dbg & 64)) return 0;
   if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9 ||
       (double)a.B * a.H * a.W * a.ldy * 2 >= 4.0e9) return 0;          // 32-bit byte offsets into each tensor
   const long GX = (long)a.B * cdiv(a.H, 16) * cdiv(a.W, 32), GY = cdiv(a.Cout, 64);
@@ -1864,10 +1892,12 @@ inline int launch_stage(Conv3x3Args& a, int grid, hipStream_t s) {
   a.tilesY = cdiv(a.H, 16);
   a.tilesX = cdiv(a.W, 32);
   const bool resident = a.c0 + a.c1 <= 64;             // one or two chunks: the whole filter fits the two stages
-  auto kern = a.stat_part ? (resident ? conv3x3_stage_kernel<2, false, true> : conv3x3_stage_kernel<2, false, false>)
-                          : (resident ? conv3x3_stage_kernel<0, true, true> : conv3x3_stage_kernel<0, true, false>);
-  static unsigned long long attr[4] = {0, 0, 0, 0};
-  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr[(a.stat_part ? 2 : 0) + (resident ? 1 : 0)])) return rc;
+  const int form = a.stat_part ? 1 : (a.ep_scale ? 2 : 0);
+  auto kern = form == 1 ? (resident ? conv3x3_stage_kernel<2, false, true> : conv3x3_stage_kernel<2, false, false>)
+            : form == 2 ? (resident ? conv3x3_stage_kernel<0, false, true, true> : conv3x3_stage_kernel<0, false, false, true>)
+                        : (resident ? conv3x3_stage_kernel<0, true, true> : conv3x3_stage_kernel<0, true, false>);
+  static unsigned long long attr[6] = {0, 0, 0, 0, 0, 0};
+  if (int rc = s2s_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds, &attr[form * 2 + (resident ? 1 : 0)])) return rc;
   const int GX = a.B * a.tilesY * a.tilesX, GY = cdiv(a.Cout, 64);
   a.xsp = GX % 8 == 0 ? 8 : 0; a.xsn = 1;
   a.stat_carry = a.stat_part != nullptr;

@@ -161,6 +161,32 @@ def test_conv3x3_staged_kernel(case):
         assert relerr(s[1], (yb * yb).sum((0, 2, 3))) < 2e-4
 
 
+@pytest.mark.parametrize("case", [(6, 250, 270, 64, 0, 64), (3, 250, 270, 64, 0, 136), (16, 100, 130, 64, 128, 64),
+                                  (6, 250, 270, 8, 0, 64)])
+def test_conv3x3_staged_eval_affine(case):
+    """The sampler's launches (eval mode: conv bias + folded BatchNorm + ReLU in the epilogue) on the staged kernel's
+    affine form: resident with one / three channel tiles, streaming from two sources, the 8-channel stem image."""
+    from stain2stain_amd import ops
+    B, H, W, c0, c1, cout = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(B, c0 + c1, H, W, generator=g) * 2 - 1
+    w = (torch.rand(cout, c0 + c1, 3, 3, generator=g) * 2 - 1) * 0.1
+    b = torch.rand(cout, generator=g) - 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.rand(cout, generator=g) - 0.5
+    ref = ((F.conv2d(rnd(x, dtype), rnd(w, dtype), b, padding=1)) * sc[None, :, None, None] + sh[None, :, None, None]).clamp_min(0)
+    xs = nhwc(x, dtype)
+    x0, x1 = xs[..., :c0], (xs[..., c0:] if c1 else None)
+    wf, _ = ops.pack_conv3x3(w.to(DEV), dtype)
+    if int(os.environ.get("S2S_CONV_STAGE", "1")) >= 1:
+        assert ops._L().s2s_conv3x3_staged(0, B, H, W, cout, c0, c1, xs.shape[3], xs.shape[3], cout, 0) > 0
+    y, _ = ops.conv3x3(x0, x1, wf, b.to(DEV), cout, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    assert relerr(nchw(y), ref) < tol_act(dtype)
+    y, _ = ops.conv3x3(x0, x1, wf, None, cout, scale=sc.to(DEV), shift=sh.to(DEV), relu=False)      # no bias, no ReLU
+    ref2 = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, padding=1) * sc[None, :, None, None] + sh[None, :, None, None]
+    assert relerr(nchw(y), ref2) < tol_act(dtype)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3_dgrad(case, dtype):
