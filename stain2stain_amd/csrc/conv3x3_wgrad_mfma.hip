@@ -244,6 +244,9 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// (Round 4 also tried the tile's 72 MFMAs as an explicit software pipeline -- X fragment of MFMA i + 5 read behind MFMA i,
+// sched_group_barrier-pinned, counted lgkmcnt(8..10) in front of every MFMA: 99-110 us against 82 us per 77-GFLOP launch and
+// 7.15-7.19 against 7.11-7.12 ms per step; the compiler's own grouping of four reads per three MFMAs stays.)
 // (Round 4 also tried a start-up phase offset per workgroup, as conv3x3_stage_kernel has: nothing gained here, 7.13 -> 7.16
 // ... 7.24 ms per step for 0.4 ... 1.8 us of offset per phase -- two workgroups per CU already drift apart.)
 // A workgroup accumulates all nine taps (one dY fragment feeds nine MFMAs).  (Rounds 2-3 also built the kernel rows over
