@@ -1868,7 +1868,8 @@ inline int stage_grid(const Conv3x3Args& a, bool stats) {
   if (!on || (a.c1 && a.c0 % 32) || (a.bias && !a.ep_scale) || (a.ep_scale && stats) || a.kpart || a.act || a.y2 ||
       !a.direct_ep || (a.dbg & 64)) return 0;
   if ((double)a.B * a.H * a.W * a.ld0 * 2 >= 4.0e9 || (double)a.B * a.H * a.W * (a.c1 ? a.ld1 : 0) * 2 >= 4.0e9 ||
-      (double)a.B * a.H * a.W * a.ldy * 2 >= 4.0e9) return 0;          // 32-bit byte offsets into each tensor
+      (double)a.B * a.H * a.W * a.ldy * 2 >= 2.0e9) return 0;          // 32-bit byte offsets into each tensor (the store's
+                                                                         // scalar offset is formed in signed arithmetic)
   const long GX = (long)a.B * cdiv(a.H, 16) * cdiv(a.W, 32), GY = cdiv(a.Cout, 64);
   const long njobs = GX * GY;
   constexpr int slots = 256;                           // one workgroup per CU (154 KB of LDS)
