@@ -126,6 +126,8 @@ STAGE_CASES = [
     (6, 250, 270, 8, 0, 64, True, 1),       # resident, ONE chunk of 8 channels (the stem on its 8-channel image)
     (6, 250, 270, 16, 0, 128, False, 1),    # resident, one chunk, two channel tiles
     (5, 120, 130, 128, 0, 192, False, 2),   # streaming, three channel tiles (a workgroup cycles through them)
+    (600, 16, 16, 64, 0, 64, True, 1),      # many small images: every tile is half outside (W = 16 < 32)
+    (300, 8, 40, 24, 0, 64, False, 1),      # H = 8 < 16, 24 input channels (one partial chunk), W tail
     (5, 120, 130, 128, 0, 192, True, 9),    # ... with statistics: never staged (3 does not divide 32), per-tap kernels
     (1, 64, 64, 128, 0, 128, True, 9),      # few tiles: per-tap kernels
 ]
