@@ -1568,8 +1568,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   // buffer_lds_probe.hip checks the destination layout and the zero fill on the device).
   constexpr unsigned OOB = 0xffffff00u;
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, (int)((long)a.nchunk * 9 * a.Cout * 64), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x0), 0, (int)(((long)a.B * a.H * a.W - 1) * a.ld0 + a.c0) * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.c1 ? x1 : x0), 0, a.c1 ? (int)(((long)a.B * a.H * a.W - 1) * a.ld1 + a.c1) * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x0), 0, (int)((((long)a.B * a.H * a.W - 1) * a.ld0 + a.c0) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.c1 ? x1 : x0), 0, a.c1 ? (int)((((long)a.B * a.H * a.W - 1) * a.ld1 + a.c1) * 2) : 0, 0x00020000);
   // the nine slabs of chunk c, channel tile n0, into stage `st` (rows swizzled as the kernels above).  Group g = wave + 8 j
   // is rows (g & 3) * 16 + drow of slab g >> 2: the row is the same for every j, only the slab (a scalar) moves
   const int wrow = (wave & 3) * 16 + drow;
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   // the offset out of range -- the hardware drops them (scripts/probe/buffer_store_probe.hip), so a store unit has no
   // branch and the chunk stays one scheduling region.
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yout, 0, (int)(((long)a.B * a.H * a.W - 1) * a.ldy + a.Cout) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yout, 0, (int)((((long)a.B * a.H * a.W - 1) * a.ldy + a.Cout) * 2), 0x00020000);
   const int nl = (kp & 1) * 16 + (kp >> 1) * 8;
   const unsigned vst = (unsigned)(cl * a.ldy + nl) * 2u;
   auto store_unit = [&](auto uc, const Tile& t) {
