@@ -1749,9 +1749,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stage_kernel(Conv3x3Args a, in
   // between "every CU issues its DMAs" and "every CU runs MFMAs" -- operand traffic and matrix work do not overlap ACROSS
   // CUs, and the 256^2 layers this kernel serves are the HBM-heaviest of the step.  Workgroup w of an XCD sleeps
   // (w mod 16) x 0.66 us before its first DMA: 16 phases over ~10 us, about one tile period of 64 -> 64.  Measured on the
-  // sustained CFM step (1000 steps, same box): 7.66 ms without, 7.62 / 7.45 / 7.45 / 7.33 / 7.20 / 7.32 ms with 0.22 /
-  // 0.44 / 0.66 / 0.88 / 1.3 / 1.8 us per phase (per-tap kernels throughout: 7.65 ms) -- the offset costs the last phase's
-  // delay once per launch and returns several times that.  (The same offset on the first round of conv3x3_dma16_kernel's
+  // sustained CFM step (1000 steps; profiles/r04_stage_ab.txt): one box 7.66 ms without, 7.62 / 7.45 / 7.45 ms with 0.22 /
+  // 0.44 / 0.66 us per phase (per-tap kernels throughout: 7.65 ms); another 7.16 ms at 0.66 against 7.20-7.33 at 0.44 /
+  // 0.88 / 1.3 / 1.8 and 7.41 per-tap -- the offset costs the last phase's delay once per launch and returns several
+  // times that.  (The same offset on the first round of conv3x3_dma16_kernel's
   // workgroups LOSES monotonically -- 7.09 / 7.14 / 7.21 / 7.30 ms for 0 / 0.22 / 0.44 / 0.66 us per phase: those layers are
   // not operand-traffic-bound -- and on conv3x3_wgrad_dma_kernel it does nothing.)
   for (int i = 0, d = 3 * (int)((blockIdx.x >> 3) & 15); i < d; ++i) __builtin_amdgcn_s_sleep(8);
